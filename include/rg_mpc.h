@@ -1,0 +1,167 @@
+/*
+ * rg_mpc.h -- C-ABI of the MI355X-native batched convex-MPC gait controller.
+ *
+ * Drop-in boundary for ONE path of nicrusso7/robot-gym: everything
+ * MPCController.get_action() does per control tick
+ * (reference robot_gym/controllers/mpc/mpc_controller.py:102-106), batched over B robots.
+ * The reference has no FFI for this path (it is pure Python calling the third-party
+ * `mpc_controller` / `mpc_osqp` modules, mpc_controller.py:6-7); the entry points below are
+ * what a maintainer's ctypes binding would load.
+ *
+ * Conventions
+ *   - return 0 on success, a negative rg_mpc_status otherwise; nothing throws across the ABI;
+ *     rg_mpc_last_error() gives the text of the last failure on a handle (or of create()).
+ *   - the CALLER owns every I/O buffer (device memory, e.g. torch-ROCm tensors passed as
+ *     data_ptr()); the library owns only per-robot persistent controller state.
+ *   - all work is enqueued on the hipStream_t passed in (NULL = default stream); no hidden
+ *     synchronisation in rg_mpc_step / rg_mpc_set_command / rg_mpc_hybrid_to_torque.
+ *   - one handle per (device, stream); calls on one handle are not thread-safe.
+ *   - inputs are float32 struct-of-arrays, component-major:  x[c*B + b]  (lane = robot loads
+ *     coalesce); outputs are row-major per robot:  action[b*60 + k].
+ */
+#ifndef RG_MPC_H
+#define RG_MPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_MPC_ABI_VERSION 1
+#define RG_MPC_MAX_HORIZON 20
+#define RG_MPC_NUM_LEGS 4
+#define RG_MPC_NUM_MOTORS 12
+#define RG_MPC_ACTION_DIM 60 /* reference model/robots/simple_motor.py:15,130 */
+
+typedef enum {
+  RG_MPC_OK = 0,
+  RG_MPC_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  RG_MPC_ERR_HIP = -2,       /* HIP runtime error (text in last_error) */
+  RG_MPC_ERR_NO_DEVICE = -3, /* no usable GPU */
+  RG_MPC_ERR_ALLOC = -4
+} rg_mpc_status;
+
+/* gait_generator.LegState of the upstream library; the reference uses the enum at
+ * model/robots/ghost/ctrl_constants.py:32-37 */
+enum { RG_LEG_SWING = 0, RG_LEG_STANCE = 1, RG_LEG_EARLY_CONTACT = 2, RG_LEG_LOSE_CONTACT = 3 };
+
+enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1 };
+
+/* Everything MPCController._setup_controller wires (mpc_controller.py:28-66) plus the
+ * upstream module defaults it does not override, as explicit fields. */
+typedef struct {
+  int32_t abi_version;      /* RG_MPC_ABI_VERSION */
+  int32_t horizon;          /* upstream _PLANNING_HORIZON_STEPS = 10 */
+  double dt_plan;           /* upstream _PLANNING_TIMESTEP = 0.025 */
+  double mass;              /* MPC_BODY_MASS      ghost/ctrl_constants.py:8 */
+  double inertia[9];        /* MPC_BODY_INERTIA   ghost/ctrl_constants.py:9 (row-major) */
+  double body_height;       /* MPC_BODY_HEIGHT    ghost/ctrl_constants.py:10 */
+  double weights[13];       /* upstream _MPC_WEIGHTS (rpy, xyz, omega, v, g) */
+  double alpha;             /* 1e-5 ; P = 2 B'WB + alpha I */
+  double mu[4];             /* friction 0.45 x4 (must all be equal) */
+  double fz_max_scale;      /* 10  : fz_max = scale * m * g */
+  double fz_min_scale;      /* 0.1 : fz_min = scale * m * g */
+  double gravity;           /* 9.8 */
+  double stance_duration[4];/* STANCE_DURATION_SECONDS ctrl_constants.py:13 */
+  double duty_factor[4];    /* DUTY_FACTOR             ctrl_constants.py:28 */
+  double init_phase[4];     /* INIT_PHASE_FULL_CYCLE   ctrl_constants.py:29 */
+  int32_t init_state[4];    /* INIT_LEG_STATE          ctrl_constants.py:32-37 */
+  double contact_phase_thresh; /* 0.1 */
+  int32_t window;           /* COMVelocityEstimator window_size=20, mpc_controller.py:36 */
+  int32_t kin_mode;         /* 0: foot_pos + jac supplied by caller; 1: computed from q on device */
+  double foot_clearance;    /* 0.01, mpc_controller.py:45 */
+  double swing_kp[3];       /* Raibert gain 0.03 */
+  double max_clearance;     /* 0.1 swing apex */
+  double hip[12];           /* DEFAULT_HIP_POSITIONS ghost/constants.py:31-36 */
+  double motor_kp[12];      /* MOTOR_POSITION_GAINS ghost/motor_constants.py:13 */
+  double motor_kd[12];      /* MOTOR_VELOCITY_GAINS :15 */
+  double motor_dir[12];     /* MOTOR_DIRECTION :11 */
+  double motor_off[12];     /* MOTOR_OFFSET :9 */
+  /* URDF leg chains (util/pybullet_data/robots/ghost.urdf), [leg][joint][xyz] */
+  double jxyz[36];
+  double jrpy[36];
+  double jaxis[36];
+  double toe_xyz[12];
+  double toe_com[12];
+  double base_com[3];
+  int32_t ik_iters;         /* fixed damped-Newton iteration count (12) */
+  int32_t solver;           /* RG_SOLVER_* */
+  double ik_damping;        /* lambda^2 */
+  double ik_max_step;       /* rad per iteration */
+  /* friction-cone ADMM */
+  int32_t admm_iters;       /* fixed iteration count (150) */
+  int32_t reserved0;
+  double admm_rho;          /* 1e-4 */
+  double admm_relax;        /* 1.8 */
+} rg_mpc_config;
+
+/* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per
+ * field (model/robots/robot.py). */
+typedef struct {
+  const float *rpy;       /* [3][B] GetBaseRollPitchYaw            robot.py:79-86 */
+  const float *rpy_rate;  /* [3][B] GetBaseRollPitchYawRate (body) robot.py:205-213 */
+  const float *v_world;   /* [3][B] GetBaseVelocity                robot.py:172-178 */
+  const float *quat;      /* [4][B] GetTrueBaseOrientation x,y,z,w robot.py:180-183 */
+  const float *q;         /* [12][B] GetMotorAngles                robot.py:231-236 */
+  const float *foot_pos;  /* [12][B] GetFootPositionsInBaseFrame   robot.py:389-397 (kin_mode 0; may be NULL in kin_mode 1) */
+  const float *jac;       /* [36][B] per leg d foot_i/d joint_j, index leg*9+i*3+j:
+                             columns 6+joint of calculateJacobian, controllers/mpc/kinematics.py:25-27,47-51 (kin_mode 0) */
+  const int32_t *contact; /* [4][B] GetFootContacts                robot.py:215-229 */
+  const float *cmd;       /* [3][B] (vx,vy,wz) AFTER the robot offsets of mpc_controller.py:90-95; NULL = use rg_mpc_set_command */
+} rg_mpc_state_ptrs;
+
+typedef struct {
+  float *action;           /* [B][60] hybrid command (q*,kp,qd*,kd,tau)x12 -- required */
+  float *grf;              /* [B][12] first-step contact forces (optional, may be NULL) */
+  float *tau_stance;       /* [B][12] J' f for all 12 joints (optional) */
+  int32_t *leg_state;      /* [B][4] (optional) */
+  int32_t *desired_state;  /* [B][4] (optional) */
+  float *phase;            /* [B][4] normalized phase (optional) */
+  float *foot_target;      /* [B][12] swing trajectory point (optional) */
+  float *v_body;           /* [B][3] filtered body-frame CoM velocity (optional) */
+} rg_mpc_out_ptrs;
+
+typedef struct rg_mpc_handle rg_mpc_handle;
+
+/* Allocates per-robot persistent state for `batch` robots on HIP device `device`.
+ * Mirrors MPCController.__init__/_setup_controller (mpc_controller.py:18-66). */
+int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mpc_handle **out);
+
+/* LocomotionController.reset() (via MPCController.reset, mpc_controller.py:108-109) for the
+ * robots idx[0..n) (HOST pointer; NULL = all).  t0 = clock value at reset
+ * (core/simulation.py:141-142).  Swing start positions are latched from the foot positions
+ * of the first rg_mpc_step after the reset. */
+int rg_mpc_reset(rg_mpc_handle *h, const int32_t *idx_host, int32_t n, double t0, void *stream);
+
+/* Same, with one clock value per robot: t0_host[k] applies to idx_host[k] (idx NULL = robots
+ * 0..n-1).  Lets a vectorised env reset its sub-envs at different times in one call. */
+int rg_mpc_reset_at(rg_mpc_handle *h, const int32_t *idx_host, const double *t0_host, int32_t n, void *stream);
+
+/* MPCController.update_controller_params (mpc_controller.py:83-100): cmd = [3][B] device
+ * pointer, offsets already added.  Copied into the handle. */
+int rg_mpc_set_command(rg_mpc_handle *h, const float *cmd, void *stream);
+
+/* MPCController.get_action (mpc_controller.py:102-106) for all B robots at clock value t. */
+int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const rg_mpc_out_ptrs *out, void *stream);
+
+/* RobotMotorModel.convert_to_torque, HYBRID branch (model/robots/simple_motor.py:128-140):
+ * action [B][60], q/qd [12][B] -> tau [B][12].  Device pointers. */
+int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream);
+
+/* Introspection for benches/profilers: number of robots per stance-leg count in the last
+ * step (HOST out[5]); synchronises the stream. */
+int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream);
+
+/* Names of the kernels launched by rg_mpc_step, for matching rocprof rows. */
+const char *rg_mpc_kernel_names(void);
+
+void rg_mpc_destroy(rg_mpc_handle *h);
+const char *rg_mpc_last_error(const rg_mpc_handle *h); /* h may be NULL: error of the last failed create */
+int rg_mpc_abi_version(void);
+int rg_mpc_config_size(void); /* sizeof(rg_mpc_config), for binding self-checks */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""Batched MPC controller: B quadrupeds per call, HIP kernels underneath.
+
+Host-side mirror of MPCController (reference controllers/mpc/mpc_controller.py:14-113) with
+every per-robot scalar promoted to a [.., B] device tensor.  PyTorch-ROCm is used only for
+device buffers and the current stream; all arithmetic happens in librg_mpc.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from robot_gym_amd.core import mpc_abi
+from robot_gym_amd.core.config import MPCConfig
+
+STATE_FIELDS = (("rpy", 3, torch.float32), ("rpy_rate", 3, torch.float32), ("v_world", 3, torch.float32),
+                ("quat", 4, torch.float32), ("q", 12, torch.float32), ("foot_pos", 12, torch.float32),
+                ("jac", 36, torch.float32), ("contact", 4, torch.int32))
+
+
+class BatchedMPCController:
+    """update_controller_params / get_action / reset for a batch of robots on one GPU."""
+
+    MOTOR_CONTROL_MODE = 3  # simple_motor.MOTOR_CONTROL_HYBRID, reference mpc_controller.py:16
+
+    def __init__(self, batch, cfg: MPCConfig = None, device=None, extra_outputs=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedMPCController needs a HIP device (no CPU fallback)")
+        self.cfg = cfg or MPCConfig.for_robot("ghost")
+        self.batch = int(batch)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._handle = mpc_abi.MpcHandle(self.cfg, self.batch, self.device.index or 0)
+        B, dev = self.batch, self.device
+        self.cmd = torch.zeros(3, B, dtype=torch.float32, device=dev)
+        self.action = torch.zeros(B, 60, dtype=torch.float32, device=dev)
+        self.extra = {}
+        if extra_outputs:
+            self.extra = dict(
+                grf=torch.zeros(B, 12, dtype=torch.float32, device=dev),
+                tau_stance=torch.zeros(B, 12, dtype=torch.float32, device=dev),
+                leg_state=torch.zeros(B, 4, dtype=torch.int32, device=dev),
+                desired_state=torch.zeros(B, 4, dtype=torch.int32, device=dev),
+                phase=torch.zeros(B, 4, dtype=torch.float32, device=dev),
+                foot_target=torch.zeros(B, 12, dtype=torch.float32, device=dev),
+                v_body=torch.zeros(B, 3, dtype=torch.float32, device=dev),
+            )
+        self._out = mpc_abi.COutPtrs()
+        self._out.action = self.action.data_ptr()
+        for k, v in self.extra.items():
+            setattr(self._out, k, v.data_ptr())
+        self._offsets = torch.tensor([self.cfg.vx_offset, self.cfg.vy_offset, self.cfg.wz_offset],
+                                     dtype=torch.float32, device=dev).view(3, 1)
+        self._set_command_called = False
+
+    # -- stream plumbing -------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- plugin surface, batched -----------------------------------------------------
+    def update_controller_params(self, params):
+        """params: [B,2] (vx, wz) or [B,3] (vx, vy, wz) -- reference mpc_controller.py:83-100."""
+        p = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if p.dim() == 1:
+            p = p.unsqueeze(0).expand(self.batch, -1)
+        if p.shape[0] != self.batch or p.shape[1] not in (2, 3):
+            raise ValueError(f"params must be [B,2] or [B,3], got {tuple(p.shape)}")
+        if p.shape[1] == 2:
+            vx, wz = p[:, 0], p[:, 1]
+            vy = torch.zeros_like(vx)
+        else:
+            vx, vy, wz = p[:, 0], p[:, 1], p[:, 2]
+        self.cmd.copy_(torch.stack([vx, vy, wz], 0) + self._offsets)
+        self._handle.set_command(self.cmd.data_ptr(), self._stream())
+        self._set_command_called = True
+
+    def set_raw_command(self, cmd_3xB):
+        """cmd already offset-corrected, component-major [3,B]."""
+        self.cmd.copy_(cmd_3xB)
+        self._handle.set_command(self.cmd.data_ptr(), self._stream())
+        self._set_command_called = True
+
+    def get_action(self, t, state):
+        """state: dict of component-major device tensors (STATE_FIELDS).  Returns action [B,60]
+        (device tensor, overwritten by the next call) -- reference mpc_controller.py:102-106."""
+        sp = mpc_abi.CStatePtrs()
+        for name, comps, dt in STATE_FIELDS:
+            tsr = state.get(name)
+            if tsr is None:
+                if name in ("foot_pos", "jac") and self.cfg.kin_mode == 1:
+                    continue
+                raise KeyError(f"state is missing {name!r}")
+            if tsr.dtype != dt or tuple(tsr.shape) != (comps, self.batch) or not tsr.is_contiguous() or tsr.device != self.device:
+                raise ValueError(f"state[{name!r}] must be contiguous {dt} [{comps},{self.batch}] on {self.device}")
+            setattr(sp, name, tsr.data_ptr())
+        sp.cmd = None  # use the command stored by update_controller_params
+        self._handle.step(t, sp, self._out, self._stream())
+        return self.action
+
+    def reset(self, idx=None, t0=0.0):
+        """LocomotionController.reset for robots idx (None = all) -- reference mpc_controller.py:108-109."""
+        if idx is not None:
+            idx = [int(i) for i in (idx.tolist() if hasattr(idx, "tolist") else idx)]
+        self._handle.reset(idx, t0, self._stream())
+
+    def reset_at(self, t0s, idx=None):
+        """Per-robot reset clock values (phase offsets between sub-envs)."""
+        self._handle.reset_at(list(t0s), None if idx is None else list(idx), self._stream())
+
+    def hybrid_to_torque(self, action, q, qd, out=None):
+        """Motor model, HYBRID branch (reference model/robots/simple_motor.py:128-140)."""
+        if out is None:
+            out = torch.empty(self.batch, 12, dtype=torch.float32, device=self.device)
+        self._handle.hybrid_to_torque(action.data_ptr(), q.data_ptr(), qd.data_ptr(), out.data_ptr(), self._stream())
+        return out
+
+    def bin_counts(self):
+        return self._handle.last_bin_counts(self._stream())
+
+    @staticmethod
+    def get_standing_action():
+        return 0., 0.  # reference mpc_controller.py:111-113
+
+    def close(self):
+        self._handle.close()

@@ -1,0 +1,92 @@
+"""MPC configuration: the reference's wiring made explicit.
+
+`MPCConfig.for_robot(name)` reproduces what MPCController._setup_controller passes
+(reference controllers/mpc/mpc_controller.py:28-66) from the robot's constants, plus the
+defaults of the upstream motion_imitation==0.0.5 modules that the reference does not
+override (horizon, plan dt, QP weights, friction, alpha ...).  Those upstream defaults are
+NOT in the reference tree; they are restated from the published library and are therefore
+ordinary, documented configuration here.
+"""
+from dataclasses import dataclass, field, asdict
+from typing import Tuple
+
+import numpy as np
+
+from robot_gym_amd.model.robots.robot_constants import ROBOTS, RobotConstants
+
+SOLVER_ADMM = 0
+SOLVER_ACTIVE_SET = 1
+
+
+@dataclass
+class MPCConfig:
+    horizon: int = 10
+    dt_plan: float = 0.025
+    mass: float = 190 / 9.8
+    inertia: Tuple[float, ...] = (0.07335, 0, 0, 0, 0.25068, 0, 0, 0, 0.25447)
+    body_height: float = 0.42
+    weights: Tuple[float, ...] = (5, 5, 0.2, 0, 0, 10, 0.5, 0.5, 0.2, 0.2, 0.2, 0.1, 0)
+    alpha: float = 1e-5
+    mu: Tuple[float, ...] = (0.45,) * 4
+    fz_max_scale: float = 10.0
+    fz_min_scale: float = 0.1
+    gravity: float = 9.8
+    stance_duration: Tuple[float, ...] = (0.3,) * 4
+    duty_factor: Tuple[float, ...] = (0.6,) * 4
+    init_phase: Tuple[float, ...] = (0.9, 0, 0, 0.9)
+    init_state: Tuple[int, ...] = (0, 1, 1, 0)
+    contact_phase_thresh: float = 0.1
+    window: int = 20
+    kin_mode: int = 0
+    foot_clearance: float = 0.01
+    swing_kp: Tuple[float, ...] = (0.03,) * 3
+    max_clearance: float = 0.1
+    hip: Tuple[float, ...] = ()
+    motor_kp: Tuple[float, ...] = (220.0,) * 12
+    motor_kd: Tuple[float, ...] = (1.0, 2.0, 2.0) * 4
+    motor_dir: Tuple[float, ...] = (1.0,) * 12
+    motor_off: Tuple[float, ...] = (0.0,) * 12
+    jxyz: Tuple[float, ...] = (0.0,) * 36
+    jrpy: Tuple[float, ...] = (0.0,) * 36
+    jaxis: Tuple[float, ...] = (0.0,) * 36
+    toe_xyz: Tuple[float, ...] = (0.0,) * 12
+    toe_com: Tuple[float, ...] = (0.0,) * 12
+    base_com: Tuple[float, ...] = (0.0,) * 3
+    ik_iters: int = 12
+    solver: int = SOLVER_ADMM
+    ik_damping: float = 1e-10
+    ik_max_step: float = 0.5
+    admm_iters: int = 150
+    admm_rho: float = 1e-4
+    admm_relax: float = 1.8
+    # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
+    vx_offset: float = 0.0
+    vy_offset: float = 0.0
+    wz_offset: float = 0.0
+    robot: str = "ghost"
+
+    @classmethod
+    def for_robot(cls, robot="ghost", **overrides):
+        rc: RobotConstants = ROBOTS[robot] if isinstance(robot, str) else robot
+        ch = rc.chain
+        flat = lambda key: tuple(float(v) for leg in ch["legs"] for row in leg[key] for v in row)
+        flat1 = lambda key: tuple(float(v) for leg in ch["legs"] for v in leg[key])
+        cfg = cls(
+            mass=rc.mpc_body_mass, inertia=tuple(float(x) for x in rc.mpc_body_inertia), body_height=rc.mpc_body_height,
+            stance_duration=tuple(rc.stance_duration_seconds), duty_factor=tuple(rc.duty_factor),
+            init_phase=tuple(float(x) for x in rc.init_phase_full_cycle), init_state=tuple(int(s) for s in rc.init_leg_state),
+            hip=tuple(float(v) for p in rc.default_hip_positions for v in p),
+            motor_kp=tuple(rc.motor_position_gains), motor_kd=tuple(rc.motor_velocity_gains),
+            motor_dir=tuple(rc.motor_direction), motor_off=tuple(rc.motor_offset),
+            jxyz=flat("xyz"), jrpy=flat("rpy"), jaxis=flat("axis"), toe_xyz=flat1("toe_xyz"), toe_com=flat1("toe_com"),
+            base_com=tuple(float(v) for v in ch["base_com"]),
+            vx_offset=rc.vx_offset, vy_offset=rc.vy_offset, wz_offset=rc.wz_offset, robot=rc.name,
+        )
+        for k, v in overrides.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown MPCConfig field {k!r}")
+            setattr(cfg, k, v)
+        return cfg
+
+    def to_dict(self):
+        return asdict(self)

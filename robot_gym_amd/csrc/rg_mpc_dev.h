@@ -1,0 +1,193 @@
+// rg_mpc_dev.h -- device-side types and math for the batched convex-MPC controller (gfx950).
+// Everything here is float64: the condensed QP Hessian has condition number ~4e5
+// (alpha = 1e-5 against O(1) angular terms) and CDNA4 issues v_fma_f64 at half the
+// packed-f32 rate, so f64 costs < 2x and buys the 1e-4 torque tolerance with margin.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RG_MAXH 20
+#define RG_REC_N 88  // doubles per robot in the front->QP record
+
+// record layout (doubles)
+#define REC_ROLL 0
+#define REC_PITCH 1
+#define REC_COMZ 2
+#define REC_OMEGA 3
+#define REC_VBODY 6
+#define REC_CMD 9
+#define REC_FEETW 12
+#define REC_IWINV 24
+#define REC_INVCP 33
+#define REC_TANP 34
+#define REC_JAC 35
+#define REC_SWINGQ 71
+#define REC_EMIT 83
+#define REC_CONTACT 84
+
+struct DevCfg {
+  int H, window, kin_mode, ik_iters, admm_iters, pad0;
+  double dt, mass, inv_mass, body_height, alpha, mu, fz_min, fz_max, g;
+  double Iinv[9];
+  double w[13];
+  double stance_dur[4], duty[4], init_phase[4];
+  int init_state[4];
+  double contact_thresh, foot_clearance, max_clearance;
+  double swing_kp[3];
+  double hip[12];
+  double kp[12], kd[12], mdir[12], moff[12];
+  double jxyz[36];    // [leg][joint][3]
+  double jRf[108];    // [leg][joint][9] fixed rotation of the joint origin (Rz Ry Rx of URDF rpy)
+  double jaxis[36];   // normalised
+  double tip[12];     // toe_xyz + toe_com
+  double base_com[3];
+  double ik_damping, ik_max_step;
+  double rho, relax;
+  double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
+  double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
+};
+
+struct DevState {
+  double *reset_time;   // [B]
+  int *flags;           // [B] bit0 need_latch, bit1 first_update
+  int *last_desired;    // [B] 4 x 1 bit
+  float *ring;          // [3][W][B]   (inputs are f32, stored losslessly)
+  int *ring_len, *ring_head;  // [B]
+  double *fsum, *fcorr; // [3][B]
+  double *latched;      // [12][B]
+  double *swing_q;      // [12][B]
+  int *swing_valid;     // [B] 12-bit mask
+  float *cmd;           // [3][B] rg_mpc_set_command copy
+  double *rec;          // [B][RG_REC_N]
+  int *bins;            // [5][B]
+  int *counts;          // [8]
+};
+
+struct DevIn {
+  const float *rpy, *rpy_rate, *v_world, *quat, *q, *foot_pos, *jac, *cmd;
+  const int *contact;
+};
+struct DevOut {
+  float *action, *grf, *tau_stance, *phase, *foot_target, *v_body;
+  int *leg_state, *desired_state;
+};
+
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void m3mul(const double *a, const double *b, double *c) {
+  double t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) c[i] = t[i];
+}
+__device__ __forceinline__ void m3vec(const double *a, const double *v, double *o) {
+  double t0 = a[0] * v[0] + a[1] * v[1] + a[2] * v[2];
+  double t1 = a[3] * v[0] + a[4] * v[1] + a[5] * v[2];
+  double t2 = a[6] * v[0] + a[7] * v[1] + a[8] * v[2];
+  o[0] = t0; o[1] = t1; o[2] = t2;
+}
+
+// Leg forward kinematics + joint-space Jacobian of the toe COM in the base (COM) frame,
+// generic 3-revolute URDF chain.  Replaces reference controllers/mpc/kinematics.py:13-30
+// and model/robots/robot.py:367-397.
+__device__ inline void leg_fk(const DevCfg *c, int leg, const double qm[3], double p[3], double J[9]) {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0};
+  double axw[3][3], org[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    double t[3];
+    m3vec(R, &c->jxyz[(leg * 3 + j) * 3], t);
+    o[0] += t[0]; o[1] += t[1]; o[2] += t[2];
+    m3mul(R, &c->jRf[(leg * 3 + j) * 9], R);
+    const double *ax = &c->jaxis[(leg * 3 + j) * 3];
+    m3vec(R, ax, axw[j]);
+    org[j][0] = o[0]; org[j][1] = o[1]; org[j][2] = o[2];
+    int m = leg * 3 + j;
+    double th = qm[j] * c->mdir[m] + c->moff[m];
+    double s, cs;
+    sincos(th, &s, &cs);
+    double C = 1.0 - cs, x = ax[0], y = ax[1], z = ax[2];
+    double Rq[9] = {cs + x * x * C, x * y * C - z * s, x * z * C + y * s,
+                    y * x * C + z * s, cs + y * y * C, y * z * C - x * s,
+                    z * x * C - y * s, z * y * C + x * s, cs + z * z * C};
+    m3mul(R, Rq, R);
+  }
+  double t[3];
+  m3vec(R, &c->tip[leg * 3], t);
+  double pf[3] = {o[0] + t[0], o[1] + t[1], o[2] + t[2]};
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    double d0 = pf[0] - org[j][0], d1 = pf[1] - org[j][1], d2 = pf[2] - org[j][2];
+    J[0 * 3 + j] = axw[j][1] * d2 - axw[j][2] * d1;
+    J[1 * 3 + j] = axw[j][2] * d0 - axw[j][0] * d2;
+    J[2 * 3 + j] = axw[j][0] * d1 - axw[j][1] * d0;
+  }
+  p[0] = pf[0] - c->base_com[0]; p[1] = pf[1] - c->base_com[1]; p[2] = pf[2] - c->base_com[2];
+}
+
+__device__ inline bool solve3(const double *A, const double *b, double *x) {
+  double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  if (det == 0.0) return false;
+  double inv = 1.0 / det;
+  double i01 = (A[2] * A[7] - A[1] * A[8]) * inv, i02 = (A[1] * A[5] - A[2] * A[4]) * inv;
+  double i11 = (A[0] * A[8] - A[2] * A[6]) * inv, i12 = (A[2] * A[3] - A[0] * A[5]) * inv;
+  double i21 = (A[1] * A[6] - A[0] * A[7]) * inv, i22 = (A[0] * A[4] - A[1] * A[3]) * inv;
+  x[0] = c00 * inv * b[0] + i01 * b[1] + i02 * b[2];
+  x[1] = c01 * inv * b[0] + i11 * b[1] + i12 * b[2];
+  x[2] = c02 * inv * b[0] + i21 * b[1] + i22 * b[2];
+  return true;
+}
+
+// Fixed-count damped-Newton IK (dq = J'(JJ' + lambda^2 I)^-1 e), started from the current
+// joint angles.  Replaces reference controllers/mpc/kinematics.py:98-133.
+__device__ inline void leg_ik(const DevCfg *c, int leg, const double target[3], const double q0[3], double qo[3]) {
+  double q[3] = {q0[0], q0[1], q0[2]};
+  for (int it = 0; it < c->ik_iters; it++) {
+    double p[3], J[9], e[3], A[9], y[3];
+    leg_fk(c, leg, q, p, J);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) J[3 * i + j] *= c->mdir[3 * leg + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[i] = target[i] - p[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        A[3 * i + j] = J[3 * i] * J[3 * j] + J[3 * i + 1] * J[3 * j + 1] + J[3 * i + 2] * J[3 * j + 2] + (i == j ? c->ik_damping : 0.0);
+    if (!solve3(A, e, y)) break;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double dq = J[j] * y[0] + J[3 + j] * y[1] + J[6 + j] * y[2];
+      dq = fmin(fmax(dq, -c->ik_max_step), c->ik_max_step);
+      q[j] += dq;
+    }
+  }
+  qo[0] = q[0]; qo[1] = q[1]; qo[2] = q[2];
+}
+
+// Euclidean projection onto { |x| <= mu z, |y| <= mu z, lo <= z <= hi }.
+__device__ __forceinline__ void proj_pyramid(double a, double b, double c, double mu, double lo, double hi,
+                                             double &x, double &y, double &z) {
+  double aa = fabs(a), bb = fabs(b);
+  double mn = fmin(aa, bb), mx = fmax(aa, bb);
+  double inv_mu = 1.0 / mu;
+  double zA = (c + mu * (aa + bb)) / (1.0 + 2.0 * mu * mu);
+  double zB = (c + mu * mx) / (1.0 + mu * mu);
+  double zz = (zA < mn * inv_mu) ? zA : ((zB < mx * inv_mu) ? zB : c);
+  zz = fmin(fmax(zz, lo), hi);
+  double lim = mu * zz;
+  x = fmin(fmax(a, -lim), lim);
+  y = fmin(fmax(b, -lim), lim);
+  z = zz;
+}
+
+__device__ __forceinline__ void neumaier_add(double &sum, double &corr, double v) {
+  double ns = sum + v;
+  if (fabs(sum) >= fabs(v)) corr += (sum - ns) + v; else corr += (v - ns) + sum;
+  sum = ns;
+}

@@ -1,0 +1,119 @@
+"""Shared glue for parity tests: same seeded float32 states -> CPU oracle and -> HIP path."""
+import numpy as np
+
+from robot_gym_amd.core.config import MPCConfig
+from robot_gym_amd import synthetic
+
+
+def oracle_config(O, cfg: MPCConfig):
+    c = O.default_config()
+    dct = cfg.to_dict()
+    import ctypes as C
+    for name, _ in c._fields_:
+        if name not in dct:
+            continue
+        v = dct[name]
+        cur = getattr(c, name)
+        if isinstance(cur, (int, float)):
+            setattr(c, name, type(cur)(v))
+        else:
+            arr = np.ctypeslib.as_array(cur)
+            arr[...] = np.asarray(v, dtype=arr.dtype).reshape(arr.shape)
+    return c
+
+
+def oracle_inputs(O, state, cmd_off, contact):
+    """component-major float32 arrays -> structured INPUT_DTYPE[B] (float64 upcast of the same values)."""
+    B = state["rpy"].shape[1]
+    inp = np.zeros(B, dtype=O.INPUT_DTYPE)
+    inp["rpy"] = state["rpy"].T.astype(np.float64)
+    inp["rpy_rate"] = state["rpy_rate"].T.astype(np.float64)
+    inp["v_world"] = state["v_world"].T.astype(np.float64)
+    inp["quat"] = state["quat"].T.astype(np.float64)
+    inp["q"] = state["q"].T.astype(np.float64)
+    inp["foot_pos"] = state["foot_pos"].T.astype(np.float64).reshape(B, 4, 3)
+    inp["jac"] = state["jac"].T.astype(np.float64).reshape(B, 4, 3, 3)
+    inp["contact"] = contact.T
+    inp["cmd"] = cmd_off.T.astype(np.float64)
+    return inp
+
+
+def cmd_with_offsets(cfg, cmd):
+    """reference mpc_controller.py:90-95, in float32 like the device path."""
+    off = np.array([cfg.vx_offset, cfg.vy_offset, cfg.wz_offset], dtype=np.float32).reshape(3, 1)
+    return (cmd.astype(np.float32) + off).astype(np.float32)
+
+
+def run_oracle(O, cfg, state, cmd, t_off, ticks, dt=0.01, nthreads=0, jitter=None):
+    ocfg = oracle_config(O, cfg)
+    B = state["rpy"].shape[1]
+    ob = O.OracleBatch(ocfg, B, 0.0, nthreads)
+    for b in range(B):
+        ob.states[b].reset_time = -float(t_off[b])
+    outs = []
+    coff = cmd_with_offsets(cfg, cmd)
+    for k in range(ticks):
+        t = k * dt
+        st = perturb(state, k, jitter)
+        contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"])
+        outs.append(ob.step(t, oracle_inputs(O, st, coff, contact)))
+    return outs
+
+
+def perturb(state, k, jitter):
+    """Deterministic per-tick variation of the synthetic state so filters/latches see changing data."""
+    if not jitter:
+        return state
+    st = dict(state)
+    f = np.float32(1.0 + jitter * np.sin(0.7 * k))
+    st["v_world"] = (state["v_world"] * f).astype(np.float32)
+    st["foot_pos"] = (state["foot_pos"] * np.float32(1.0 + 0.2 * jitter * np.cos(0.3 * k))).astype(np.float32)
+    return st
+
+
+def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0"):
+    import torch
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    B = state["rpy"].shape[1]
+    ctl = BatchedMPCController(B, cfg, device=device)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()).to(device))
+    outs = []
+    for k in range(ticks):
+        t = k * dt
+        st = perturb(state, k, jitter)
+        contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"])
+        dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).to(device) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+        dev["contact"] = torch.from_numpy(contact).to(device)
+        act = ctl.get_action(t, dev)
+        torch.cuda.synchronize()
+        o = {"action": act.cpu().numpy().copy()}
+        for kx, v in ctl.extra.items():
+            o[kx] = v.cpu().numpy().copy()
+        o["bins"] = ctl.bin_counts()
+        outs.append(o)
+    ctl.close()
+    return outs
+
+
+def compare_tick(og, oo, tol=1e-4):
+    """Returns dict of error metrics between one GPU tick (dict) and one oracle tick (struct array)."""
+    act_g, act_o = og["action"].astype(np.float64), oo["action"].astype(np.float64)
+    B = act_g.shape[0]
+    a_g, a_o = act_g.reshape(B, 12, 5), act_o.reshape(B, 12, 5)
+    tau_g, tau_o = a_g[:, :, 4], a_o[:, :, 4]
+    scale = np.maximum(np.abs(tau_o).max(1), 1.0)
+    tau_rel = (np.abs(tau_g - tau_o).max(1) / scale)
+    q_abs = np.abs(a_g[:, :, 0] - a_o[:, :, 0]).max()
+    gains = np.abs(a_g[:, :, [1, 2, 3]] - a_o[:, :, [1, 2, 3]]).max()
+    res = dict(tau_rel_max=float(tau_rel.max()), tau_rel_argmax=int(tau_rel.argmax()), q_abs=float(q_abs), gains=float(gains))
+    if "grf" in og:
+        g_o = oo["grf"]
+        gs = np.maximum(np.abs(g_o).max(1), 1.0)
+        res["grf_rel_max"] = float((np.abs(og["grf"].astype(np.float64) - g_o).max(1) / gs).max())
+    if "leg_state" in og:
+        res["leg_state_mismatch"] = int((og["leg_state"] != oo["leg_state"]).sum())
+        res["desired_mismatch"] = int((og["desired_state"] != oo["desired"]).sum())
+        res["phase_abs"] = float(np.abs(og["phase"].astype(np.float64) - oo["phase"]).max())
+        res["phase_bits"] = int((og["phase"] != oo["phase"].astype(np.float32)).sum())
+    return res
