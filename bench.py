@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC controller steps/sec (whole node), batch=4096 quadrupeds per GPU,
+horizon=10 (BASELINE.json).  One "step" = one rg_mpc_step over one batch of synthetic robot
+states already resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, hipEvent-timed over
+the timed region, algorithmic bytes from DESIGN.md section 5) and, at N=1, "cpu_baseline" (the float64
+C oracle = a port of the algorithm, OpenMP over robots, on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+BATCH_PER_GPU = 4096
+HORIZON = 10
+# algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off)
+ALGO_BYTES_PER_STEP = 1110
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_device_state(cfg, B, seed, device):
+    from robot_gym_amd import synthetic
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed)
+    contact = synthetic.gait_consistent_contacts(cfg, t_off, state["_flip"])
+    dev = {n: torch.from_numpy(np.ascontiguousarray(state[n])).to(device)
+           for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+    dev["contact"] = torch.from_numpy(contact).to(device)
+    return state, cmd, t_off, contact, dev
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """Time the oracle (port) on the host cores on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    from tests import helpers
+    from robot_gym_amd import synthetic
+    cores = os.cpu_count() or 1
+    Bs = 512
+    state, cmd, t_off = synthetic.make_states(Bs, cfg, seed=0)
+    ocfg = helpers.oracle_config(O, cfg)
+    ob = O.OracleBatch(ocfg, Bs, 0.0, cores)
+    for b in range(Bs):
+        ob.states[b].reset_time = -float(t_off[b])
+    coff = helpers.cmd_with_offsets(cfg, cmd)
+    contact = synthetic.gait_consistent_contacts(cfg, t_off, state["_flip"])
+    inp = helpers.oracle_inputs(O, state, coff, contact)
+    ob.step(0.0, inp)  # warm
+    t0 = time.perf_counter()
+    ticks = 0
+    while True:
+        ob.step(0.01 * (ticks + 1), inp)
+        ticks += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or ticks >= 200:
+            break
+    return {"value": Bs * ticks / el, "unit": "controller steps/s", "cores": cores, "kind": "port",
+            "sample": f"{Bs} robots x {ticks} ticks of the batch=4096 workload (seed 0), float64 C oracle with exact active-set QP, OpenMP over robots"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="robots per GPU")
+    ap.add_argument("--allgather", action="store_true", help="also all-gather the action slab over RCCL inside the timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--admm-iters", type=int, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    over = {} if args.admm_iters is None else {"admm_iters": args.admm_iters}
+    cfg = MPCConfig.for_robot("ghost", horizon=HORIZON, **over)
+    B = args.batch
+    # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard
+    state, cmd, t_off, contact, dev = make_device_state(cfg, B, seed=rank, device=device)
+    ctl = BatchedMPCController(B, cfg, device=device, extra_outputs=False)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()).to(device))
+    gathered = torch.empty(world * B, 60, dtype=torch.float32, device=device) if (args.allgather and world > 1) else None
+
+    def one_step(k):
+        act = ctl.get_action(0.01 * k, dev)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, act)
+
+    for k in range(args.warmup):
+        one_step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctl._handle.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    nprof, kms, robots = ctl._handle.profile_end(ctl._stream())
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_units = world * B * args.steps
+        value = total_units / elapsed
+        names = ["rg_front_kernel", "rg_qp_admm_kernel(nc=1)", "rg_qp_admm_kernel(nc=2)", "rg_qp_admm_kernel(nc=3)", "rg_qp_admm_kernel(nc=4)"]
+        units = [B, robots[1], robots[2], robots[3], robots[4]]
+        dom = int(np.argmax(kms[:5]))
+        dur_s = kms[dom] * 1e-3
+        achieved = (ALGO_BYTES_PER_STEP * units[dom] / dur_s) / 1e9 if dur_s > 0 else 0.0
+        out = {
+            "metric": "MPC controller steps/sec (whole node), batch=4096 quadrupeds, horizon=10",
+            "value": value, "unit": "controller steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch={B} quadrupeds per GPU, horizon={HORIZON}, randomised (vx,vy,wz) commands (BASELINE configs[2])",
+                       "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} iters={cfg.admm_iters}",
+                       "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None), "sharding": f"{world} x {B} robots, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,
+                         "avg_launch_ms": kms[dom],
+                         "kernel_ms": dict(zip(names + ["step_total"], [round(x, 4) for x in kms])),
+                         "note": "path is LDS/latency-bound, not HBM-bound (SURVEY.md 7.3-2); see DESIGN.md section 5 for the FLOP/LDS view"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:  # the baseline is a reported extra, never the product path
+                out["cpu_baseline"] = {"value": None, "unit": "controller steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    ctl.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,6 +153,14 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
  * step (HOST out[5]); synchronises the stream. */
 int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream);
 
+/* Per-kernel timing with hipEvents recorded on the step's own stream, between the launches of
+ * rg_mpc_step.  begin(max_steps) arms it; every following rg_mpc_step records one event after
+ * each launch; end() synchronises the stream, returns the number of recorded steps and fills
+ * avg_ms[6] = average duration of {front, qp nc=1, qp nc=2, qp nc=3, qp nc=4, whole step}
+ * and robots[5] = robots per stance-leg bin in the last recorded step. */
+int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps);
+int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void *stream);
+
 /* Names of the kernels launched by rg_mpc_step, for matching rocprof rows. */
 const char *rg_mpc_kernel_names(void);
 

@@ -57,6 +57,7 @@ class MPCConfig:
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
     admm_iters: int = 150
+    reserved0: int = 0  # bit0: force the LDS-resident QP kernel (A/B, generic horizon path)
     admm_rho: float = 1e-4
     admm_relax: float = 1.8
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)

@@ -45,7 +45,7 @@ class COutPtrs(C.Structure):
 
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
-           "rg_mpc_last_bin_counts", "rg_mpc_kernel_names", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_profile_begin", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -75,6 +75,10 @@ def load_library(path=None):
     L.rg_mpc_hybrid_to_torque.restype = i32
     L.rg_mpc_last_bin_counts.argtypes = [fp, C.POINTER(i32 * 5), fp]
     L.rg_mpc_last_bin_counts.restype = i32
+    L.rg_mpc_profile_begin.argtypes = [fp, i32]
+    L.rg_mpc_profile_begin.restype = i32
+    L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
+    L.rg_mpc_profile_end.restype = i32
     L.rg_mpc_kernel_names.restype = C.c_char_p
     L.rg_mpc_destroy.argtypes = [fp]
     L.rg_mpc_destroy.restype = None
@@ -96,7 +100,7 @@ def make_cconfig(cfg):
     c = CConfig()
     c.abi_version = ABI_VERSION
     for name, ctype in CConfig._fields_:
-        if name in ("abi_version", "reserved0"):
+        if name in ("abi_version",):
             continue
         v = getattr(cfg, name)
         if isinstance(v, (tuple, list)) or hasattr(v, "__len__"):
@@ -155,6 +159,17 @@ class MpcHandle:
         out = (i32 * 5)()
         self._check(self._lib.rg_mpc_last_bin_counts(self._h, C.byref(out), stream))
         return list(out)
+
+    def profile_begin(self, max_steps):
+        self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))
+
+    def profile_end(self, stream=None):
+        ms = (C.c_float * 6)()
+        rb = (i32 * 5)()
+        n = self._lib.rg_mpc_profile_end(self._h, C.byref(ms), C.byref(rb), stream)
+        if n < 0:
+            self._check(n)
+        return n, list(ms), list(rb)
 
     def kernel_names(self):
         return self._lib.rg_mpc_kernel_names().decode().split(",")

@@ -399,6 +399,233 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
 }
 
 // ------------------------------------------------------------------------------------
+// QP kernel, register-resident variant (the fast path).
+// Thread t = (row r = t / SPLIT, part s = t % SPLIT) keeps C = N / SPLIT consecutive entries of
+// row r of the symmetric matrix in VGPRs with compile-time indices.  The MI355X register file
+// (512 KB per CU) is 3x its LDS, so this lifts the LDS-capacity occupancy limit of the
+// LDS-resident kernel; LDS only carries the pivot row (sweep) / the rhs vector (ADMM) as
+// broadcast reads.
+//   sweep step kp:  pivot lanes publish row kp (with entry kp replaced by d-1 so that the
+//                   unconditional FMA leaves cc = A_ik/d in column kp of every other row),
+//                   pivot lanes scale their own row; its diagonal then holds +1 instead of
+//                   -1/d, which is never read by another row and is undone in the mat-vec
+//                   through dfix = 1 + 1/d.
+// ------------------------------------------------------------------------------------
+template <int NC, int H, int SPLIT>
+__global__ void __launch_bounds__(((3 * NC * H * SPLIT + 63) / 64) * 64)
+rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B) {
+  constexpr int m3 = 3 * NC;
+  constexpr int N = m3 * H;
+  constexpr int C = N / SPLIT;
+  constexpr int NT = ((N * SPLIT + 63) / 64) * 64;
+  static_assert(N % SPLIT == 0 && C % m3 == 0 && C % 2 == 0, "row split must align with (leg,axis) blocks");
+  const int tid = threadIdx.x;
+  const int r = tid / SPLIT, s = tid % SPLIT;
+  const bool active = r < N;
+  const int col0 = s * C;
+  const int count = st.counts[NC];
+  constexpr int NP = (N + 2 + 1) & ~1;  // pivot buffer stride (doubles), even for 16-B alignment
+  double *pbuf = smem;               // 2 * NP   ping-pong pivot row; [N] = pivot value d
+  double *vv = pbuf + 2 * NP;        // N  rhs vector
+  double *wv = vv + N;               // N  projection input
+  double *GU = wv + N;               // m3*m3
+  double *GV = GU + m3 * m3;
+  double *c1 = GV + m3 * m3;         // N
+  double *c2 = c1 + N;               // N
+  double *Bw = c2 + N;               // 3*m3
+  double *TBw = Bw + 3 * m3;         // 3*m3
+  double *rec = TBw + 3 * m3;        // RG_REC_N
+  double *grf = rec + RG_REC_N;      // 24
+  double *tabN = grf + 24;           // H*H
+  double *tabS = tabN + H * H;       // H*H
+  const double rho = c->rho, relax = c->relax, mu = c->mu, lo = c->fz_min, hi = c->fz_max, dt = c->dt;
+  for (int e = tid; e < H * H; e += NT) { tabN[e] = 2.0 * c->Ntab[e]; tabS[e] = 2.0 * c->Stab[e]; }
+
+  for (int work = blockIdx.x; work < count; work += gridDim.x) {
+    const int b = st.bins[(size_t)NC * B + work];
+    __syncthreads();
+    for (int e = tid; e < RG_REC_N; e += NT) rec[e] = st.rec[(size_t)b * RG_REC_N + e];
+    if (tid < 24) grf[tid] = 0.0;
+    __syncthreads();
+    const int cmask = (int)rec[REC_CONTACT];
+    int legs[4], kk = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) if ((cmask >> l) & 1) legs[kk++] = l;
+    if (tid < m3) {
+      int l = legs[tid / 3], d = tid % 3;
+      const double *rr = &rec[REC_FEETW + 3 * l];
+      double s0 = (d == 0) ? 0.0 : (d == 1 ? -rr[2] : rr[1]);
+      double s1 = (d == 0) ? rr[2] : (d == 1 ? 0.0 : -rr[0]);
+      double s2 = (d == 0) ? -rr[1] : (d == 1 ? rr[0] : 0.0);
+      const double *Iw = &rec[REC_IWINV];
+      double b0 = Iw[0] * s0 + Iw[1] * s1 + Iw[2] * s2;
+      double b1 = Iw[3] * s0 + Iw[4] * s1 + Iw[5] * s2;
+      double b2 = Iw[6] * s0 + Iw[7] * s1 + Iw[8] * s2;
+      Bw[tid] = b0; Bw[m3 + tid] = b1; Bw[2 * m3 + tid] = b2;
+      TBw[tid] = rec[REC_INVCP] * b0; TBw[m3 + tid] = b1; TBw[2 * m3 + tid] = rec[REC_TANP] * b0 + b2;
+    }
+    __syncthreads();
+    for (int e = tid; e < m3 * m3; e += NT) {
+      int i = e / m3, j = e % m3;
+      double gu = c->w[6] * Bw[i] * Bw[j] + c->w[7] * Bw[m3 + i] * Bw[m3 + j] + c->w[8] * Bw[2 * m3 + i] * Bw[2 * m3 + j];
+      double gv = c->w[0] * TBw[i] * TBw[j] + c->w[1] * TBw[m3 + i] * TBw[m3 + j] + c->w[2] * TBw[2 * m3 + i] * TBw[2 * m3 + j];
+      if (i % 3 == j % 3) { gu += c->w[9 + i % 3] * c->inv_mass * c->inv_mass; gv += c->w[3 + i % 3] * c->inv_mass * c->inv_mass; }
+      GU[e] = gu * dt * dt;
+      GV[e] = gv * dt * dt * dt * dt;
+    }
+    if (tid < N) {
+      int a = tid / m3, i = tid % m3;
+      double kd = (double)(a + 1) * dt;
+      const double *om = &rec[REC_OMEGA], *vb = &rec[REC_VBODY], *cm = &rec[REC_CMD];
+      double e_r = rec[REC_ROLL] + kd * rec[REC_INVCP] * om[0];
+      double e_p = rec[REC_PITCH] + kd * om[1];
+      double e_y = kd * (rec[REC_TANP] * om[0] + om[2]) - kd * cm[2];
+      double e_x = kd * vb[0] - kd * cm[0];
+      double e_yy = kd * vb[1] - kd * cm[1];
+      double e_z = rec[REC_COMZ] + kd * vb[2] - 0.5 * kd * kd * c->g - c->body_height;
+      double e_w0 = om[0], e_w1 = om[1], e_w2 = om[2] - cm[2];
+      double e_v0 = vb[0] - cm[0], e_v1 = vb[1] - cm[1], e_v2 = vb[2] - kd * c->g;
+      int d = i % 3;
+      double ev = (d == 0) ? c->w[9] * e_v0 : (d == 1 ? c->w[10] * e_v1 : c->w[11] * e_v2);
+      double ep = (d == 0) ? c->w[3] * e_x : (d == 1 ? c->w[4] * e_yy : c->w[5] * e_z);
+      c1[tid] = dt * (Bw[i] * c->w[6] * e_w0 + Bw[m3 + i] * c->w[7] * e_w1 + Bw[2 * m3 + i] * c->w[8] * e_w2 + c->inv_mass * ev);
+      c2[tid] = dt * dt * (TBw[i] * c->w[0] * e_r + TBw[m3 + i] * c->w[1] * e_p + TBw[2 * m3 + i] * c->w[2] * e_y + c->inv_mass * ep);
+    }
+    __syncthreads();
+    // ---- my C entries of row r of (P + rho I), and q_r ----
+    double row[C];
+    double qi = 0.0;
+    {
+      const int a = active ? r / m3 : 0, i = active ? r % m3 : 0;
+      for (int kq = a; kq < H; kq++) qi += c1[kq * m3 + i] + ((double)(kq - a) + 0.5) * c2[kq * m3 + i];
+      qi *= 2.0;
+      const int bb0 = s * (C / m3);
+#pragma unroll
+      for (int jj = 0; jj < C; jj++) {
+        const int bb = bb0 + jj / m3, j = jj % m3;
+        double v = tabN[a * H + bb] * GU[j * m3 + i] + tabS[a * H + bb] * GV[j * m3 + i];
+        if (col0 + jj == r) v += c->alpha + rho;
+        row[jj] = v;
+      }
+    }
+    // ---- symmetric sweep, rows in registers ----
+    double dfix = 0.0;
+    const int my_diag_part = r / C;  // which part of row r holds the diagonal
+    for (int kp = 0; kp < N; kp++) {
+      double *pb = pbuf + (kp & 1) * NP;
+      if (active && r == kp) {
+#pragma unroll
+        for (int jj = 0; jj < C; jj += 2) *reinterpret_cast<double2 *>(&pb[col0 + jj]) = make_double2(row[jj], row[jj + 1]);
+        if (s == kp / C) { double d = pb[kp]; pb[kp] = d - 1.0; pb[N] = d; }
+      }
+      __syncthreads();
+      if (active) {
+        const double invd = 1.0 / pb[N];
+        if (r == kp) {
+#pragma unroll
+          for (int jj = 0; jj < C; jj++) row[jj] *= invd;
+          if (s == my_diag_part) dfix = 1.0 + invd;
+        } else {
+          const double ncc = -pb[r] * invd;
+#pragma unroll
+          for (int jj = 0; jj < C; jj += 2) {
+            double2 p2 = *reinterpret_cast<const double2 *>(&pb[col0 + jj]);
+            row[jj] = fma(ncc, p2.x, row[jj]);
+            row[jj + 1] = fma(ncc, p2.y, row[jj + 1]);
+          }
+        }
+      }
+    }
+    // row now holds -(P + rho I)^-1 entries (diagonal offset by dfix)
+    // ---- over-relaxed ADMM ----
+    double z = (active && (r % 3) == 2) ? lo : 0.0, y = 0.0;
+    const int blk = active ? r - r % 3 : 0, dax = r % 3;
+    for (int it = 0; it < c->admm_iters; it++) {
+      const double rhs = rho * (z - y) - qi;
+      if (active && s == 0) vv[r] = rhs;
+      __syncthreads();
+      double part = 0.0;
+      if (active) {
+#pragma unroll
+        for (int jj = 0; jj < C; jj += 2) {
+          double2 v2 = *reinterpret_cast<const double2 *>(&vv[col0 + jj]);
+          part = fma(row[jj], v2.x, part);
+          part = fma(row[jj + 1], v2.y, part);
+        }
+        if (s == my_diag_part) part -= dfix * rhs;
+      }
+#pragma unroll
+      for (int o = 1; o < SPLIT; o <<= 1) part += __shfl_xor(part, o);
+      const double u = -part;
+      const double w = relax * u + (1.0 - relax) * z + y;
+      if (active && s == 0) wv[r] = w;
+      __syncthreads();
+      if (active) {
+        double px, py, pz;
+        proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, px, py, pz);
+        const double zn = (dax == 0) ? px : (dax == 1 ? py : pz);
+        y = w - zn;
+        z = zn;
+      }
+    }
+    if (active && s == 0 && r < m3) grf[3 * legs[r / 3] + r % 3] = -z;
+    __syncthreads();
+    if (tid < 12) {
+      int leg = tid / 3, j = tid % 3;
+      const double *J = &rec[REC_JAC + 9 * leg];
+      double tau = (grf[3 * leg] * J[j] + grf[3 * leg + 1] * J[3 + j] + grf[3 * leg + 2] * J[6 + j]) * c->mdir[tid];
+      grf[12 + tid] = tau;
+      if (out.grf) out.grf[(size_t)b * 12 + tid] = (float)grf[tid];
+      if (out.tau_stance) out.tau_stance[(size_t)b * 12 + tid] = (float)tau;
+    }
+    __syncthreads();
+    if (tid < 60) {
+      int j = tid / 5, f = tid % 5;
+      int emit = ((int)rec[REC_EMIT] >> j) & 1;
+      float v;
+      if (emit) v = (f == 0) ? (float)rec[REC_SWINGQ + j] : (f == 1 ? (float)c->kp[j] : (f == 3 ? (float)c->kd[j] : 0.f));
+      else v = (f == 4) ? (float)grf[12 + j] : 0.f;
+      out.action[(size_t)b * 60 + tid] = v;
+    }
+  }
+}
+
+template <int NC, int H, int SPLIT>
+static size_t qp_reg_lds_bytes() {
+  constexpr int m3 = 3 * NC, N = m3 * H, NP = (N + 2 + 1) & ~1;
+  return sizeof(double) * (size_t)(2 * NP + 2 * N + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
+}
+
+template <int NC, int H, int SPLIT>
+static hipError_t launch_qp_reg(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
+  constexpr int NT = ((3 * NC * H * SPLIT + 63) / 64) * 64;
+  int grid = cu_count * 8;
+  if (grid > B) grid = B;
+  const size_t lds = qp_reg_lds_bytes<NC, H, SPLIT>();
+  rg_qp_admm_reg_kernel<NC, H, SPLIT><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
+  return hipGetLastError();
+}
+
+// returns true if a register-resident instantiation exists for (nc, H)
+static bool launch_qp_reg_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err) {
+  *err = hipSuccess;
+  if (H == 10) {
+    switch (nc) {
+      case 1: *err = launch_qp_reg<1, 10, 1>(dcfg, st, dout, B, cu, s); return true;
+      case 2: *err = launch_qp_reg<2, 10, 1>(dcfg, st, dout, B, cu, s); return true;
+      case 3: *err = launch_qp_reg<3, 10, 1>(dcfg, st, dout, B, cu, s); return true;
+      case 4: *err = launch_qp_reg<4, 10, 2>(dcfg, st, dout, B, cu, s); return true;
+    }
+  } else if (H == 20) {
+    switch (nc) {
+      case 1: *err = launch_qp_reg<1, 20, 1>(dcfg, st, dout, B, cu, s); return true;
+      case 2: *err = launch_qp_reg<2, 20, 2>(dcfg, st, dout, B, cu, s); return true;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------
 __global__ void rg_reset_kernel(const DevCfg *__restrict__ c, DevState st, const int *idx, const double *t0v, int n, double t0, int B) {
@@ -443,6 +670,10 @@ struct rg_mpc_handle {
   size_t lds_bytes[5] = {0, 0, 0, 0, 0};
   std::vector<void *> allocs;
   std::string err;
+  // optional per-kernel event timing
+  std::vector<hipEvent_t> ev;   // 6 events per profiled step
+  int prof_max = 0, prof_n = 0;
+  bool force_lds_kernel = false;
 };
 
 static thread_local std::string g_create_err;
@@ -547,7 +778,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -556,6 +787,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   *out = nullptr;
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
+  h->force_lds_kernel = (cfg->reserved0 & 1) != 0;  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   if (rc) { g_create_err = h->err; delete h; return rc; }
   int ndev = 0;
@@ -596,7 +828,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
 void rg_mpc_destroy(rg_mpc_handle *h) {
   if (!h) return;
   hipSetDevice(h->device);
-  for (void *p : h->allocs) hipFree(p);
+  for (void *p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -652,12 +885,23 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
   HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 8, s));
+  hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * 6] : nullptr;
+  if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);
   HIPCHK(h, hipGetLastError());
+  if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
   for (int nc = 1; nc <= 4; nc++) {
     const int n = 3 * nc * H;
+    if (!h->force_lds_kernel) {
+      hipError_t lerr;
+      if (launch_qp_reg_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr)) {
+        HIPCHK(h, lerr);
+        if (pev) HIPCHK(h, hipEventRecord(pev[1 + nc], s));
+        continue;
+      }
+    }
     size_t lds = h->lds_bytes[nc];
-    if (lds == 0) continue; // TODO(round 2): out-of-LDS variant for H=20 with 3-4 stance legs
+    if (lds == 0) { if (pev) HIPCHK(h, hipEventRecord(pev[1 + nc], s)); continue; } // TODO(round 2): out-of-LDS variant for H=20 with 3-4 stance legs
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
@@ -667,8 +911,39 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     else if (n <= 128) hipLaunchKernelGGL(rg_qp_admm_kernel<128>, dim3(grid), dim3(128), lds, s, h->dcfg, h->st, dout, nc, B);
     else hipLaunchKernelGGL(rg_qp_admm_kernel<256>, dim3(grid), dim3(256), lds, s, h->dcfg, h->st, dout, nc, B);
     HIPCHK(h, hipGetLastError());
+    if (pev) HIPCHK(h, hipEventRecord(pev[1 + nc], s));
   }
+  if (pev) h->prof_n++;
   return RG_MPC_OK;
+}
+
+int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
+  if (!h || max_steps < 1 || max_steps > 100000) { if (h) h->err = "profile_begin: bad max_steps"; return RG_MPC_ERR_INVALID; }
+  HIPCHK(h, hipSetDevice(h->device));
+  while ((int)h->ev.size() < max_steps * 6) {
+    hipEvent_t e;
+    HIPCHK(h, hipEventCreate(&e));
+    h->ev.push_back(e);
+  }
+  h->prof_max = max_steps; h->prof_n = 0;
+  return RG_MPC_OK;
+}
+
+int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void *stream) {
+  if (!h || !avg_ms6) { if (h) h->err = "profile_end: null output"; return RG_MPC_ERR_INVALID; }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  int n = h->prof_n;
+  h->prof_max = 0;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < n; k++) {
+    hipEvent_t *e = &h->ev[(size_t)k * 6];
+    for (int j = 0; j < 5; j++) { float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e[j], e[j + 1])); acc[j] += ms; }
+    float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[5])); acc[5] += ms;
+  }
+  for (int j = 0; j < 6; j++) avg_ms6[j] = n > 0 ? (float)(acc[j] / n) : 0.f;
+  if (robots5) HIPCHK(h, hipMemcpy(robots5, h->st.counts, sizeof(int) * 5, hipMemcpyDeviceToHost));
+  return n;
 }
 
 int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream) {
