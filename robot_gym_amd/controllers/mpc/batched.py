@@ -17,6 +17,23 @@ STATE_FIELDS = (("rpy", 3, torch.float32), ("rpy_rate", 3, torch.float32), ("v_w
                 ("jac", 36, torch.float32), ("contact", 4, torch.int32))
 
 
+def command_with_offsets(params, offsets, batch):
+    """(vx, wz) or (vx, vy, wz) per robot -> component-major [3,B] command with the robot's
+    offsets added: lin = [vx + VX_OFFSET, vy + VY_OFFSET, 0], ang = wz + WZ_OFFSET
+    (reference controllers/mpc/mpc_controller.py:83-95).  Works on any torch device."""
+    p = params
+    if p.dim() == 1:
+        p = p.unsqueeze(0).expand(batch, -1)
+    if p.shape[0] != batch or p.shape[1] not in (2, 3):
+        raise ValueError(f"params must be [B,2] or [B,3], got {tuple(p.shape)}")
+    if p.shape[1] == 2:
+        vx, wz = p[:, 0], p[:, 1]
+        vy = torch.zeros_like(vx)
+    else:
+        vx, vy, wz = p[:, 0], p[:, 1], p[:, 2]
+    return torch.stack([vx, vy, wz], 0) + offsets.view(3, 1)
+
+
 class BatchedMPCController:
     """update_controller_params / get_action / reset for a batch of robots on one GPU."""
 
@@ -59,16 +76,7 @@ class BatchedMPCController:
     def update_controller_params(self, params):
         """params: [B,2] (vx, wz) or [B,3] (vx, vy, wz) -- reference mpc_controller.py:83-100."""
         p = torch.as_tensor(params, dtype=torch.float32, device=self.device)
-        if p.dim() == 1:
-            p = p.unsqueeze(0).expand(self.batch, -1)
-        if p.shape[0] != self.batch or p.shape[1] not in (2, 3):
-            raise ValueError(f"params must be [B,2] or [B,3], got {tuple(p.shape)}")
-        if p.shape[1] == 2:
-            vx, wz = p[:, 0], p[:, 1]
-            vy = torch.zeros_like(vx)
-        else:
-            vx, vy, wz = p[:, 0], p[:, 1], p[:, 2]
-        self.cmd.copy_(torch.stack([vx, vy, wz], 0) + self._offsets)
+        self.cmd.copy_(command_with_offsets(p, self._offsets, self.batch))
         self._handle.set_command(self.cmd.data_ptr(), self._stream())
         self._set_command_called = True
 

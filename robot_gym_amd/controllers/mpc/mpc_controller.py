@@ -1,0 +1,97 @@
+"""Drop-in `MPCController` for the reference's PyBullet environments (batch = 1 plumbing).
+
+Same plugin surface as the reference class (robot_gym/controllers/mpc/mpc_controller.py:14-113):
+class attribute MOTOR_CONTROL_MODE, __init__(robot, get_time_since_reset), kinematics_model,
+setup_ui_params / read_ui_params, update_controller_params, get_action, reset,
+get_standing_action.  Instead of driving the third-party Python/C++ stack per robot it pushes
+the robot's state through the HIP controller with B = 1; registering it under
+robot_gym/util/cli/mapper.py:7-9 makes it selectable.
+"""
+import numpy as np
+import torch
+
+from robot_gym_amd.controllers.controller import Controller
+from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+from robot_gym_amd.controllers.mpc.kinematics import ChainKinematics, PybulletKinematics
+from robot_gym_amd.core.config import MPCConfig
+from robot_gym_amd.model.robots.robot_constants import ROBOTS
+
+MOTOR_CONTROL_HYBRID = 3  # reference model/robots/simple_motor.py:11
+
+
+def config_from_robot(robot, robot_name=None, **overrides):
+    """MPCConfig from the live robot's constant modules, i.e. the values the reference reads in
+    _setup_controller (mpc_controller.py:28-66) -- GetCtrlConstants / GetConstants / GetMotorConstants."""
+    ctrl, geom, motor = robot.GetCtrlConstants(), robot.GetConstants(), robot.GetMotorConstants()
+    if robot_name is None:
+        hips = tuple(tuple(float(v) for v in p) for p in geom.DEFAULT_HIP_POSITIONS)
+        robot_name = next((n for n, rc in ROBOTS.items() if tuple(tuple(float(v) for v in p) for p in rc.default_hip_positions) == hips), "ghost")
+    cfg = MPCConfig.for_robot(robot_name)
+    cfg.mass = float(ctrl.MPC_BODY_MASS)
+    cfg.inertia = tuple(float(x) for x in ctrl.MPC_BODY_INERTIA)
+    cfg.body_height = float(ctrl.MPC_BODY_HEIGHT)
+    cfg.stance_duration = tuple(float(x) for x in ctrl.STANCE_DURATION_SECONDS)
+    cfg.duty_factor = tuple(float(x) for x in ctrl.DUTY_FACTOR)
+    cfg.init_phase = tuple(float(x) for x in ctrl.INIT_PHASE_FULL_CYCLE)
+    cfg.init_state = tuple(int(getattr(s, "value", s)) for s in ctrl.INIT_LEG_STATE)
+    cfg.vx_offset, cfg.vy_offset, cfg.wz_offset = float(ctrl.VX_OFFSET), float(ctrl.VY_OFFSET), float(ctrl.WZ_OFFSET)
+    cfg.hip = tuple(float(v) for p in geom.DEFAULT_HIP_POSITIONS for v in p)
+    cfg.motor_kp = tuple(float(x) for x in motor.MOTOR_POSITION_GAINS)
+    cfg.motor_kd = tuple(float(x) for x in motor.MOTOR_VELOCITY_GAINS)
+    cfg.motor_dir = tuple(float(x) for x in motor.MOTOR_DIRECTION)
+    cfg.motor_off = tuple(float(x) for x in motor.MOTOR_OFFSET)
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class MPCController(Controller):
+    MOTOR_CONTROL_MODE = MOTOR_CONTROL_HYBRID
+
+    def __init__(self, robot, get_time_since_reset, device=None, config=None):
+        super().__init__(robot, get_time_since_reset)
+        self._cfg = config or config_from_robot(robot)
+        self._chain = ChainKinematics(self._cfg)
+        self._kinematics = PybulletKinematics(robot, self._chain)
+        self._batched = BatchedMPCController(1, self._cfg, device=device, extra_outputs=True)
+        self._dev = self._batched.device
+        self.update_controller_params((0.0, 0.0, 0.0))
+
+    @property
+    def kinematics_model(self):
+        return self._kinematics
+
+    @staticmethod
+    def setup_ui_params(pybullet_client):
+        return tuple(pybullet_client.addUserDebugParameter(n, -2., 2., 0.) for n in ("Vx", "Vy", "Wz"))
+
+    @staticmethod
+    def read_ui_params(pybullet_client, ui):
+        return tuple(pybullet_client.readUserDebugParameter(i) for i in ui)
+
+    def update_controller_params(self, params):
+        if len(params) not in (2, 3):
+            raise ValueError("params must be (vx, wz) or (vx, vy, wz)")
+        self._batched.update_controller_params(torch.tensor([list(map(float, params))], dtype=torch.float32))
+
+    def _gather_state(self):
+        rb = self._robot
+        f = lambda a, n: torch.tensor(np.asarray(a, dtype=np.float32).reshape(n, 1), device=self._dev)
+        jac = np.stack([self._kinematics.leg_jacobian(leg) for leg in range(4)])
+        return {
+            "rpy": f(rb.GetBaseRollPitchYaw(), 3), "rpy_rate": f(rb.GetBaseRollPitchYawRate(), 3),
+            "v_world": f(rb.GetBaseVelocity(), 3), "quat": f(rb.GetTrueBaseOrientation(), 4),
+            "q": f(rb.GetMotorAngles(), 12), "foot_pos": f(rb.GetFootPositionsInBaseFrame(), 12), "jac": f(jac, 36),
+            "contact": torch.tensor(np.asarray(rb.GetFootContacts(), dtype=np.int32).reshape(4, 1), device=self._dev),
+        }
+
+    def get_action(self):
+        act = self._batched.get_action(self.get_time_since_reset(), self._gather_state())
+        return act[0].cpu().numpy()
+
+    def reset(self):
+        self._batched.reset(None, t0=self.get_time_since_reset())
+
+    @staticmethod
+    def get_standing_action():
+        return 0., 0.

@@ -258,6 +258,7 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
   double *grf = rec + RG_REC_N;      // 12 forces + 12 torques
   const double *Nt = c->Ntab, *St = c->Stab;
   const double rho = c->rho, relax = c->relax, mu = c->mu, lo = c->fz_min, hi = c->fz_max;
+  const double kA = 1.0 / (1.0 + 2.0 * mu * mu), kB = 1.0 / (1.0 + mu * mu);
   const double dt = c->dt;
 
   for (int work = blockIdx.x; work < count; work += gridDim.x) {
@@ -368,7 +369,7 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
       if (tid < n) {
         int blk = tid - tid % 3;
         double px, py, pz;
-        proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, px, py, pz);
+        proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, kA, kB, px, py, pz);
         int d = tid % 3;
         double zn = (d == 0) ? px : (d == 1 ? py : pz);
         y = wv[tid] - zn;
@@ -409,16 +410,16 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
 //                   unconditional FMA leaves cc = A_ik/d in column kp of every other row),
 //                   pivot lanes scale their own row; its diagonal then holds +1 instead of
 //                   -1/d, which is never read by another row and is undone in the mat-vec
-//                   through dfix = 1 + 1/d.
+//                   (see the branch-free form in the kernel body).
 // ------------------------------------------------------------------------------------
-template <int NC, int H, int SPLIT>
-__global__ void __launch_bounds__(((3 * NC * H * SPLIT + 63) / 64) * 64)
+template <int NC, int H, int SPLIT, int MINW>
+__global__ void __launch_bounds__(((3 * NC * H * SPLIT + 63) / 64) * 64, MINW)
 rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B) {
   constexpr int m3 = 3 * NC;
   constexpr int N = m3 * H;
   constexpr int C = N / SPLIT;
   constexpr int NT = ((N * SPLIT + 63) / 64) * 64;
-  static_assert(N % SPLIT == 0 && C % m3 == 0 && C % 2 == 0, "row split must align with (leg,axis) blocks");
+  static_assert(N % SPLIT == 0 && C % 2 == 0, "row split must give an even number of entries per lane");
   const int tid = threadIdx.x;
   const int r = tid / SPLIT, s = tid % SPLIT;
   const bool active = r < N;
@@ -439,6 +440,7 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
   double *tabN = grf + 24;           // H*H
   double *tabS = tabN + H * H;       // H*H
   const double rho = c->rho, relax = c->relax, mu = c->mu, lo = c->fz_min, hi = c->fz_max, dt = c->dt;
+  const double kA = 1.0 / (1.0 + 2.0 * mu * mu), kB = 1.0 / (1.0 + mu * mu);
   for (int e = tid; e < H * H; e += NT) { tabN[e] = 2.0 * c->Ntab[e]; tabS[e] = 2.0 * c->Stab[e]; }
 
   for (int work = blockIdx.x; work < count; work += gridDim.x) {
@@ -499,44 +501,41 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
       const int a = active ? r / m3 : 0, i = active ? r % m3 : 0;
       for (int kq = a; kq < H; kq++) qi += c1[kq * m3 + i] + ((double)(kq - a) + 0.5) * c2[kq * m3 + i];
       qi *= 2.0;
-      const int bb0 = s * (C / m3);
 #pragma unroll
       for (int jj = 0; jj < C; jj++) {
-        const int bb = bb0 + jj / m3, j = jj % m3;
+        const int bb = (col0 + jj) / m3, j = (col0 + jj) % m3;
         double v = tabN[a * H + bb] * GU[j * m3 + i] + tabS[a * H + bb] * GV[j * m3 + i];
         if (col0 + jj == r) v += c->alpha + rho;
         row[jj] = v;
       }
     }
-    // ---- symmetric sweep, rows in registers ----
-    double dfix = 0.0;
+    // ---- symmetric sweep, rows in registers, branch-free ----
+    // Every lane applies row += ncc * pivot_row' with pivot_row'[kp] = d - 1:
+    //   other rows: ncc = -A_rk/d      -> column kp becomes A_rk/d, the rest A_rj - A_rk A_kj/d
+    //   pivot row : ncc = 1/d - 1      -> row/d, and its diagonal becomes 2 - 1/d instead of -1/d.
+    // The pivot row's diagonal is never read by another row, so the constant +2 is undone in
+    // the mat-vec (part -= 2 rhs on the lane part that owns the diagonal).
     const int my_diag_part = r / C;  // which part of row r holds the diagonal
     for (int kp = 0; kp < N; kp++) {
       double *pb = pbuf + (kp & 1) * NP;
       if (active && r == kp) {
 #pragma unroll
         for (int jj = 0; jj < C; jj += 2) *reinterpret_cast<double2 *>(&pb[col0 + jj]) = make_double2(row[jj], row[jj + 1]);
-        if (s == kp / C) { double d = pb[kp]; pb[kp] = d - 1.0; pb[N] = d; }
+        if (s == kp / C) { double d = pb[kp]; pb[kp] = d - 1.0; pb[N] = 1.0 / d; }
       }
       __syncthreads();
       if (active) {
-        const double invd = 1.0 / pb[N];
-        if (r == kp) {
+        const double invd = pb[N];
+        const double ncc = (r == kp) ? invd - 1.0 : -pb[r] * invd;
 #pragma unroll
-          for (int jj = 0; jj < C; jj++) row[jj] *= invd;
-          if (s == my_diag_part) dfix = 1.0 + invd;
-        } else {
-          const double ncc = -pb[r] * invd;
-#pragma unroll
-          for (int jj = 0; jj < C; jj += 2) {
-            double2 p2 = *reinterpret_cast<const double2 *>(&pb[col0 + jj]);
-            row[jj] = fma(ncc, p2.x, row[jj]);
-            row[jj + 1] = fma(ncc, p2.y, row[jj + 1]);
-          }
+        for (int jj = 0; jj < C; jj += 2) {
+          double2 p2 = *reinterpret_cast<const double2 *>(&pb[col0 + jj]);
+          row[jj] = fma(ncc, p2.x, row[jj]);
+          row[jj + 1] = fma(ncc, p2.y, row[jj + 1]);
         }
       }
     }
-    // row now holds -(P + rho I)^-1 entries (diagonal offset by dfix)
+    // row now holds -(P + rho I)^-1 entries (diagonal offset by +2)
     // ---- over-relaxed ADMM ----
     double z = (active && (r % 3) == 2) ? lo : 0.0, y = 0.0;
     const int blk = active ? r - r % 3 : 0, dax = r % 3;
@@ -546,13 +545,23 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
       __syncthreads();
       double part = 0.0;
       if (active) {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
 #pragma unroll
-        for (int jj = 0; jj < C; jj += 2) {
-          double2 v2 = *reinterpret_cast<const double2 *>(&vv[col0 + jj]);
-          part = fma(row[jj], v2.x, part);
-          part = fma(row[jj + 1], v2.y, part);
+        for (int jj = 0; jj + 3 < C; jj += 4) {
+          double2 va = *reinterpret_cast<const double2 *>(&vv[col0 + jj]);
+          double2 vb2 = *reinterpret_cast<const double2 *>(&vv[col0 + jj + 2]);
+          p0 = fma(row[jj], va.x, p0);
+          p1 = fma(row[jj + 1], va.y, p1);
+          p2 = fma(row[jj + 2], vb2.x, p2);
+          p3 = fma(row[jj + 3], vb2.y, p3);
         }
-        if (s == my_diag_part) part -= dfix * rhs;
+        if constexpr (C % 4 != 0) {
+          double2 va = *reinterpret_cast<const double2 *>(&vv[col0 + C - 2]);
+          p0 = fma(row[C - 2], va.x, p0);
+          p1 = fma(row[C - 1], va.y, p1);
+        }
+        part = (p0 + p1) + (p2 + p3);
+        if (s == my_diag_part) part -= 2.0 * rhs;
       }
 #pragma unroll
       for (int o = 1; o < SPLIT; o <<= 1) part += __shfl_xor(part, o);
@@ -562,7 +571,7 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
       __syncthreads();
       if (active) {
         double px, py, pz;
-        proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, px, py, pz);
+        proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, kA, kB, px, py, pz);
         const double zn = (dax == 0) ? px : (dax == 1 ? py : pz);
         y = w - zn;
         z = zn;
@@ -596,13 +605,13 @@ static size_t qp_reg_lds_bytes() {
   return sizeof(double) * (size_t)(2 * NP + 2 * N + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
 }
 
-template <int NC, int H, int SPLIT>
+template <int NC, int H, int SPLIT, int MINW>
 static hipError_t launch_qp_reg(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
   constexpr int NT = ((3 * NC * H * SPLIT + 63) / 64) * 64;
   int grid = cu_count * 8;
   if (grid > B) grid = B;
   const size_t lds = qp_reg_lds_bytes<NC, H, SPLIT>();
-  rg_qp_admm_reg_kernel<NC, H, SPLIT><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
+  rg_qp_admm_reg_kernel<NC, H, SPLIT, MINW><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
   return hipGetLastError();
 }
 
@@ -611,15 +620,15 @@ static bool launch_qp_reg_dispatch(int nc, int H, const DevCfg *dcfg, const DevS
   *err = hipSuccess;
   if (H == 10) {
     switch (nc) {
-      case 1: *err = launch_qp_reg<1, 10, 1>(dcfg, st, dout, B, cu, s); return true;
-      case 2: *err = launch_qp_reg<2, 10, 1>(dcfg, st, dout, B, cu, s); return true;
-      case 3: *err = launch_qp_reg<3, 10, 1>(dcfg, st, dout, B, cu, s); return true;
-      case 4: *err = launch_qp_reg<4, 10, 2>(dcfg, st, dout, B, cu, s); return true;
+      case 1: *err = launch_qp_reg<1, 10, 1, 4>(dcfg, st, dout, B, cu, s); return true;
+      case 2: *err = launch_qp_reg<2, 10, 2, 4>(dcfg, st, dout, B, cu, s); return true;
+      case 3: *err = launch_qp_reg<3, 10, 1, 1>(dcfg, st, dout, B, cu, s); return true;
+      case 4: *err = launch_qp_reg<4, 10, 4, 4>(dcfg, st, dout, B, cu, s); return true;
     }
   } else if (H == 20) {
     switch (nc) {
-      case 1: *err = launch_qp_reg<1, 20, 1>(dcfg, st, dout, B, cu, s); return true;
-      case 2: *err = launch_qp_reg<2, 20, 2>(dcfg, st, dout, B, cu, s); return true;
+      case 1: *err = launch_qp_reg<1, 20, 1, 2>(dcfg, st, dout, B, cu, s); return true;
+      case 2: *err = launch_qp_reg<2, 20, 2, 2>(dcfg, st, dout, B, cu, s); return true;
     }
   }
   return false;

@@ -171,14 +171,15 @@ __device__ inline void leg_ik(const DevCfg *c, int leg, const double target[3], 
 }
 
 // Euclidean projection onto { |x| <= mu z, |y| <= mu z, lo <= z <= hi }.
+// kA = 1/(1+2mu^2), kB = 1/(1+mu^2) are hoisted by the caller (no divisions in the ADMM loop).
 __device__ __forceinline__ void proj_pyramid(double a, double b, double c, double mu, double lo, double hi,
-                                             double &x, double &y, double &z) {
+                                             double kA, double kB, double &x, double &y, double &z) {
   double aa = fabs(a), bb = fabs(b);
   double mn = fmin(aa, bb), mx = fmax(aa, bb);
-  double inv_mu = 1.0 / mu;
-  double zA = (c + mu * (aa + bb)) / (1.0 + 2.0 * mu * mu);
-  double zB = (c + mu * mx) / (1.0 + mu * mu);
-  double zz = (zA < mn * inv_mu) ? zA : ((zB < mx * inv_mu) ? zB : c);
+  double zA = (c + mu * (aa + bb)) * kA;
+  double zB = (c + mu * mx) * kB;
+  // region tests written without 1/mu:  zA < mn/mu  <=>  mu zA < mn
+  double zz = (mu * zA < mn) ? zA : ((mu * zB < mx) ? zB : c);
   zz = fmin(fmax(zz, lo), hi);
   double lim = mu * zz;
   x = fmin(fmax(a, -lim), lim);

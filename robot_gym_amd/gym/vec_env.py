@@ -1,0 +1,90 @@
+"""Batched VecEnv wrapper: B reference-style envs, ONE batched controller call per tick.
+
+API shape of the reference's BatchEnv (agents/ppo/tools/batch_env.py:18-115: len, indexing,
+step(actions) -> stacked (obs, reward, done, info), reset(indices)) and the per-env tick order of
+RobotGymEnv.step (gym/robot_gym_env.py:117-129): command -> controller action -> ApplyStepAction
+-> observation/reward/termination.  Physics stays per-env on the CPU (PyBullet); the wrapper
+gathers every env's robot state into component-major pinned host buffers, uploads once, runs
+rg_mpc_step for all envs, downloads the [B,60] action slab once and scatters it.
+"""
+import numpy as np
+import torch
+
+from robot_gym_amd.controllers.mpc.batched import BatchedMPCController, STATE_FIELDS
+from robot_gym_amd.controllers.mpc.mpc_controller import config_from_robot
+
+
+class MPCVecEnv:
+    def __init__(self, envs, device=None, config=None, jacobian_fn=None):
+        """envs: objects exposing `.simulation` (robot, GetTimeSinceReset, ApplyStepAction),
+        `get_observation()`, `reward()`, `termination()`, `reset()` like RobotGymEnv."""
+        if not envs:
+            raise ValueError("need at least one env")
+        self._envs = list(envs)
+        B = len(self._envs)
+        robot0 = self._envs[0].simulation.robot
+        self.cfg = config or config_from_robot(robot0)
+        self.controller = BatchedMPCController(B, self.cfg, device=device, extra_outputs=False)
+        self._dev = self.controller.device
+        self._jacobian_fn = jacobian_fn or (lambda env, leg: env.simulation.controller.kinematics_model.leg_jacobian(leg))
+        pin = torch.cuda.is_available()
+        self._host = {n: torch.zeros(c, B, dtype=dt, pin_memory=pin) for n, c, dt in STATE_FIELDS}
+        self._devbuf = {n: torch.zeros(c, B, dtype=dt, device=self._dev) for n, c, dt in STATE_FIELDS}
+        self._act_host = torch.zeros(B, 60, dtype=torch.float32, pin_memory=pin)
+        self._t = np.zeros(B)
+
+    def __len__(self):
+        return len(self._envs)
+
+    def __getitem__(self, index):
+        return self._envs[index]
+
+    def _gather(self):
+        h = {n: t.numpy() for n, t in self._host.items()}
+        for b, env in enumerate(self._envs):
+            rb = env.simulation.robot
+            h["rpy"][:, b] = rb.GetBaseRollPitchYaw()
+            h["rpy_rate"][:, b] = rb.GetBaseRollPitchYawRate()
+            h["v_world"][:, b] = rb.GetBaseVelocity()
+            h["quat"][:, b] = rb.GetTrueBaseOrientation()
+            h["q"][:, b] = rb.GetMotorAngles()
+            h["foot_pos"][:, b] = np.asarray(rb.GetFootPositionsInBaseFrame()).reshape(12)
+            h["contact"][:, b] = np.asarray(rb.GetFootContacts(), dtype=np.int32)
+            h["jac"][:, b] = np.stack([self._jacobian_fn(env, leg) for leg in range(4)]).reshape(36)
+            self._t[b] = env.simulation.GetTimeSinceReset()
+        for n in self._host:
+            self._devbuf[n].copy_(self._host[n], non_blocking=True)
+
+    def step(self, actions):
+        """actions: [B,2] or [B,3] velocity commands.  Returns stacked (obs, reward, done, info)."""
+        actions = np.asarray(actions, dtype=np.float32)
+        self.controller.update_controller_params(torch.from_numpy(actions))
+        self._gather()
+        # all sub-envs share one control clock when reset together; the controller keeps a
+        # per-robot reset time, so pass the clock of env 0 and offsets through reset_at().
+        act = self.controller.get_action(float(self._t[0]), self._devbuf)
+        self._act_host.copy_(act, non_blocking=True)
+        torch.cuda.current_stream(self._dev).synchronize()
+        a = self._act_host.numpy()
+        obs, rew, done, info = [], [], [], []
+        for b, env in enumerate(self._envs):
+            env.simulation.ApplyStepAction(a[b])
+            obs.append(np.asarray(env.get_observation()))
+            rew.append(env.reward())
+            d, i = env.termination()
+            done.append(d)
+            info.append(i)
+        return np.stack(obs), np.asarray(rew, dtype=np.float32), np.asarray(done, dtype=bool), tuple(info)
+
+    def reset(self, indices=None):
+        if indices is None:
+            indices = list(range(len(self._envs)))
+        obs = [np.asarray(self._envs[i].reset()) for i in indices]
+        t_now = float(self._envs[0].simulation.GetTimeSinceReset())
+        # controller clock for env i is (t_env0 - reset_time_i); a freshly reset env restarts at its own clock 0
+        t0 = [t_now - float(self._envs[i].simulation.GetTimeSinceReset()) for i in indices]
+        self.controller.reset_at(t0, indices)
+        return np.stack(obs)
+
+    def close(self):
+        self.controller.close()

@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (authoring container only).
+
+Needs /root/reference; writes small data files next to this script.  Nothing of the
+reference's source travels: only seeded inputs and the outputs its code produced.
+
+  motor_model.npz   RobotMotorModel.convert_to_torque, HYBRID branch
+                    (robot_gym/model/robots/simple_motor.py:85-148)
+  force_to_torque.npz  Kinematics.MapContactForceToJointTorques with a stub pybullet
+                    Jacobian (robot_gym/controllers/mpc/kinematics.py:13-53)
+  adapter.json      MPCController wiring recorded through a stub `mpc_controller` package:
+                    constructor kwargs (mpc_controller.py:28-66), update_controller_params
+                    arithmetic for 2- and 3-tuples (:83-100), get_action call order (:102-106),
+                    reset (:108-109), get_standing_action (:111-113); ghost and k3lso constants.
+"""
+import enum
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("RG_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+# ---- stub third-party `mpc_controller` (motion_imitation==0.0.5 is not installable here) ----
+CALLS = []
+
+
+class LegState(enum.Enum):
+    SWING = 0
+    STANCE = 1
+    EARLY_CONTACT = 2
+    LOSE_CONTACT = 3
+
+
+def _recording_class(name):
+    class Rec:
+        def __init__(self, *args, **kwargs):
+            self.kwargs = kwargs
+            self.nargs = len(args)
+            CALLS.append(("init", name, sorted(kwargs)))
+    Rec.__name__ = name
+    return Rec
+
+
+class LocomotionController:
+    def __init__(self, robot, gait_generator, state_estimator, swing_leg_controller, stance_leg_controller, clock):
+        self.swing_leg_controller = swing_leg_controller
+        self.stance_leg_controller = stance_leg_controller
+        self.gait_generator = gait_generator
+        self.state_estimator = state_estimator
+        self.clock = clock
+        CALLS.append(("init", "LocomotionController", ["clock", "gait_generator", "robot", "stance_leg_controller", "state_estimator", "swing_leg_controller"]))
+
+    def update(self):
+        CALLS.append(("update",))
+
+    def get_action(self):
+        CALLS.append(("get_action",))
+        return np.arange(60, dtype=np.float32)
+
+    def reset(self):
+        CALLS.append(("reset",))
+
+
+pkg = types.ModuleType("mpc_controller")
+mods = {
+    "gait_generator": dict(LegState=LegState),
+    "openloop_gait_generator": dict(OpenloopGaitGenerator=_recording_class("OpenloopGaitGenerator")),
+    "com_velocity_estimator": dict(COMVelocityEstimator=_recording_class("COMVelocityEstimator")),
+    "raibert_swing_leg_controller": dict(RaibertSwingLegController=_recording_class("RaibertSwingLegController")),
+    "torque_stance_leg_controller": dict(TorqueStanceLegController=_recording_class("TorqueStanceLegController")),
+    "locomotion_controller": dict(LocomotionController=LocomotionController),
+}
+sys.modules["mpc_controller"] = pkg
+for name, attrs in mods.items():
+    m = types.ModuleType("mpc_controller." + name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    setattr(pkg, name, m)
+    sys.modules["mpc_controller." + name] = m
+
+
+def jsonable(v):
+    if isinstance(v, enum.Enum):
+        return int(v.value)
+    if isinstance(v, (list, tuple)):
+        return [jsonable(x) for x in v]
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    if isinstance(v, (np.floating, np.integer)):
+        return v.item()
+    if isinstance(v, (int, float, str, bool)) or v is None:
+        return v
+    return f"<{type(v).__name__}>"
+
+
+def gen_motor_model():
+    from robot_gym.model.robots import simple_motor
+    from robot_gym.model.robots.ghost import motor_constants
+    rng = np.random.default_rng(1234)
+    model = simple_motor.RobotMotorModel(num_motors=12, kp=motor_constants.MOTOR_POSITION_GAINS,
+                                         kd=motor_constants.MOTOR_VELOCITY_GAINS,
+                                         motor_control_mode=simple_motor.MOTOR_CONTROL_HYBRID)
+    n = 64
+    actions = np.zeros((n, 60), dtype=np.float32)
+    # GetPDObservation (robot.py:245-252) hands float64 arrays to the motor model; keep the values
+    # float32-representable so the device path can be fed the identical numbers.
+    q = rng.uniform(-1.5, 1.5, (n, 12)).astype(np.float32).astype(np.float64)
+    qd = rng.uniform(-8, 8, (n, 12)).astype(np.float32).astype(np.float64)
+    taus = np.zeros((n, 12))
+    for k in range(n):
+        a = np.zeros((12, 5))
+        swing = rng.uniform(0, 1, 12) < 0.5
+        a[swing, 0] = rng.uniform(-1.5, 1.5, swing.sum())
+        a[swing, 1] = np.asarray(motor_constants.MOTOR_POSITION_GAINS)[swing]
+        a[swing, 3] = np.asarray(motor_constants.MOTOR_VELOCITY_GAINS)[swing]
+        a[~swing, 4] = rng.uniform(-40, 40, (~swing).sum())
+        if k % 7 == 0:  # fully general tuples too
+            a = rng.uniform(-3, 3, (12, 5)); a[:, 1] = np.abs(a[:, 1]) * 50; a[:, 3] = np.abs(a[:, 3])
+        actions[k] = a.reshape(60).astype(np.float32)
+        t, t2 = model.convert_to_torque(actions[k], q[k], qd[k], qd[k], simple_motor.MOTOR_CONTROL_HYBRID)
+        taus[k] = t
+    np.savez(os.path.join(OUT, "motor_model.npz"), action=actions, q=q, qd=qd, tau=taus,
+             index_constants=np.array([simple_motor.POSITION_INDEX, simple_motor.POSITION_GAIN_INDEX, simple_motor.VELOCITY_INDEX,
+                                       simple_motor.VELOCITY_GAIN_INDEX, simple_motor.TORQUE_INDEX, simple_motor.MOTOR_COMMAND_DIMENSION,
+                                       simple_motor.MOTOR_CONTROL_HYBRID]))
+
+
+def gen_force_to_torque():
+    from robot_gym.controllers.mpc.kinematics import Kinematics
+    from robot_gym.model.robots.ghost import motor_constants, constants
+    rng = np.random.default_rng(77)
+
+    class Bullet:
+        def __init__(self):
+            self.jv = None
+            self.calls = []
+
+        def calculateJacobian(self, robot_id, link_id, local, q, qd, qdd):
+            self.calls.append((robot_id, link_id, tuple(local), len(q)))
+            return self.jv[link_id].tolist(), None
+
+    class Robot:
+        def __init__(self, bullet, direction):
+            self.pybullet_client = bullet
+            self.GetJointStates = [(0.1 * i, 0.0) for i in range(12)]
+            self.GetRobotId = 3
+            self.GetFootLinkIds = [10, 11, 12, 13]
+            self._dir = direction
+
+        def GetConstants(self):
+            return constants
+
+        def GetMotorConstants(self):
+            mc = types.SimpleNamespace(NUM_MOTORS=12, MOTOR_DIRECTION=self._dir)
+            return mc
+
+    cases = []
+    for direction in (np.ones(12), np.array([1, -1, 1, -1, 1, 1, 1, -1, -1, 1, 1, -1.0])):
+        bullet = Bullet()
+        robot = Robot(bullet, direction)
+        kin = Kinematics(robot)
+        for k in range(8):
+            bullet.jv = {10 + leg: rng.uniform(-0.4, 0.4, (3, 18)) for leg in range(4)}
+            forces = rng.uniform(-120, 120, (4, 3))
+            taus = np.zeros(12)
+            for leg in range(4):
+                mt = kin.MapContactForceToJointTorques(leg, forces[leg])
+                assert sorted(mt) == [3 * leg, 3 * leg + 1, 3 * leg + 2]
+                for j, v in mt.items():
+                    taus[j] = v
+            jac = np.stack([bullet.jv[10 + leg][:, 6 + 3 * leg: 9 + 3 * leg] for leg in range(4)])  # [leg][i][j]
+            cases.append((direction.copy(), jac, forces, taus, np.stack([bullet.jv[10 + leg] for leg in range(4)])))
+        assert bullet.calls[0][2] == (0, 0, 0)
+    np.savez(os.path.join(OUT, "force_to_torque.npz"), direction=np.stack([c[0] for c in cases]), jac=np.stack([c[1] for c in cases]),
+             force=np.stack([c[2] for c in cases]), tau=np.stack([c[3] for c in cases]), jv_full=np.stack([c[4] for c in cases]))
+
+
+def gen_adapter():
+    from robot_gym.controllers.mpc import mpc_controller as ref_mpc
+    from robot_gym.model.robots import simple_motor
+    out = {"MOTOR_CONTROL_MODE": ref_mpc.MPCController.MOTOR_CONTROL_MODE,
+           "MOTOR_CONTROL_HYBRID": simple_motor.MOTOR_CONTROL_HYBRID,
+           "get_standing_action": list(ref_mpc.MPCController.get_standing_action()), "robots": {}}
+    for robot_name in ("ghost", "k3lso"):
+        ctrl = __import__(f"robot_gym.model.robots.{robot_name}.ctrl_constants", fromlist=["x"])
+        consts = __import__(f"robot_gym.model.robots.{robot_name}.constants", fromlist=["x"])
+        motor = __import__(f"robot_gym.model.robots.{robot_name}.motor_constants", fromlist=["x"])
+
+        class Robot:
+            pybullet_client = object()
+
+            def GetCtrlConstants(self):
+                return ctrl
+
+        CALLS.clear()
+        clock = lambda: 1.25
+        ctl = ref_mpc.MPCController(Robot(), clock)
+        inner = ctl._mpc_controller
+        rec = {"init_calls": [list(c) for c in CALLS]}
+        rec["gait_kwargs"] = {k: jsonable(v) for k, v in inner.gait_generator.kwargs.items()}
+        rec["estimator_kwargs"] = {k: jsonable(v) for k, v in inner.state_estimator.kwargs.items()}
+        rec["swing_kwargs"] = {k: jsonable(v) for k, v in inner.swing_leg_controller.kwargs.items()}
+        rec["stance_kwargs"] = {k: jsonable(v) for k, v in inner.stance_leg_controller.kwargs.items()}
+        rec["clock_is_callback"] = inner.clock is clock
+        cmds = []
+        rng = np.random.default_rng(5)
+        for params in ([0.3, -0.1], [0.3, 0.05, -0.1], [0.0, 0.0], list(rng.uniform(-1, 1, 3)), list(rng.uniform(-1, 1, 2))):
+            ctl.update_controller_params(params)
+            sw, stc = inner.swing_leg_controller, inner.stance_leg_controller
+            assert sw.desired_speed == stc.desired_speed and sw.desired_twisting_speed == stc.desired_twisting_speed
+            cmds.append({"params": [float(p) for p in params], "desired_speed": [float(x) for x in sw.desired_speed],
+                         "desired_twisting_speed": float(sw.desired_twisting_speed)})
+        rec["commands"] = cmds
+        CALLS.clear()
+        act = ctl.get_action()
+        rec["get_action_calls"] = [list(c) for c in CALLS]
+        rec["get_action_returns_inner_array"] = bool(np.array_equal(act, np.arange(60, dtype=np.float32)))
+        CALLS.clear()
+        ctl.reset()
+        rec["reset_calls"] = [list(c) for c in CALLS]
+        rec["constants"] = {
+            "MPC_BODY_MASS": ctrl.MPC_BODY_MASS, "MPC_BODY_INERTIA": list(ctrl.MPC_BODY_INERTIA), "MPC_BODY_HEIGHT": ctrl.MPC_BODY_HEIGHT,
+            "STANCE_DURATION_SECONDS": list(ctrl.STANCE_DURATION_SECONDS), "DUTY_FACTOR": list(ctrl.DUTY_FACTOR),
+            "INIT_PHASE_FULL_CYCLE": list(ctrl.INIT_PHASE_FULL_CYCLE), "INIT_LEG_STATE": [int(s.value) for s in ctrl.INIT_LEG_STATE],
+            "VX_OFFSET": ctrl.VX_OFFSET, "VY_OFFSET": ctrl.VY_OFFSET, "WZ_OFFSET": ctrl.WZ_OFFSET,
+            "DEFAULT_HIP_POSITIONS": [list(p) for p in consts.DEFAULT_HIP_POSITIONS], "INIT_MOTOR_ANGLES": consts.INIT_MOTOR_ANGLES.tolist(),
+            "START_POS": list(consts.START_POS),
+            "NUM_MOTORS": motor.NUM_MOTORS, "MOTOR_POSITION_GAINS": list(motor.MOTOR_POSITION_GAINS),
+            "MOTOR_VELOCITY_GAINS": motor.MOTOR_VELOCITY_GAINS.tolist(), "MOTOR_DIRECTION": motor.MOTOR_DIRECTION.tolist(),
+            "MOTOR_OFFSET": motor.MOTOR_OFFSET.tolist(),
+        }
+        out["robots"][robot_name] = rec
+    from robot_gym.core import sim_constants
+    out["sim_constants"] = {"ACTION_REPEAT": sim_constants.ACTION_REPEAT, "SIMULATION_TIME_STEP": sim_constants.SIMULATION_TIME_STEP}
+    from robot_gym.util.cli import flags
+    out["controller_names"] = jsonable(getattr(flags, "CONTROLLERS", None) or getattr(flags, "SUPPORTED_CONTROLLERS", None))
+    with open(os.path.join(OUT, "adapter.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    gen_motor_model()
+    gen_force_to_torque()
+    gen_adapter()
+    print("golden vectors written to", OUT)
