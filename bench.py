@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--allgather", action="store_true", help="also all-gather the action slab over RCCL inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None)
+    ap.add_argument("--reserved0", type=int, default=0, help="tuning bits passed to rg_mpc_config.reserved0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,6 +99,7 @@ def main():
     from robot_gym_amd.core.config import MPCConfig
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
     over = {} if args.admm_iters is None else {"admm_iters": args.admm_iters}
+    over["reserved0"] = args.reserved0
     cfg = MPCConfig.for_robot("ghost", horizon=HORIZON, **over)
     B = args.batch
     # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard

@@ -90,7 +90,7 @@ typedef struct {
   double ik_damping;        /* lambda^2 */
   double ik_max_step;       /* rad per iteration */
   /* friction-cone ADMM */
-  int32_t admm_iters;       /* fixed iteration count (150) */
+  int32_t admm_iters;       /* fixed iteration count (100) */
   int32_t reserved0;
   double admm_rho;          /* 1e-4 */
   double admm_relax;        /* 1.8 */

@@ -56,7 +56,7 @@ class MPCConfig:
     solver: int = SOLVER_ADMM
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
-    admm_iters: int = 150
+    admm_iters: int = 100
     reserved0: int = 0  # bit0: force the LDS-resident QP kernel (A/B, generic horizon path)
     admm_rho: float = 1e-4
     admm_relax: float = 1.8

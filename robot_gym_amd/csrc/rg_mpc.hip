@@ -233,6 +233,28 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
 // i.e. row/column i of the symmetric matrix held in LDS (stored so that a thread's
 // "row" is read at consecutive addresses across lanes: element (j, i) at j*LD + i).
 // ------------------------------------------------------------------------------------
+// Pin C row registers (see pin_row below): ten per empty asm statement.
+template <int C>
+__device__ __forceinline__ void pin_array(double (&t)[C]) {
+#pragma unroll
+  for (int i = 0; i + 9 < C; i += 10)
+    asm volatile("" : "+v"(t[i]), "+v"(t[i + 1]), "+v"(t[i + 2]), "+v"(t[i + 3]), "+v"(t[i + 4]), "+v"(t[i + 5]), "+v"(t[i + 6]), "+v"(t[i + 7]), "+v"(t[i + 8]), "+v"(t[i + 9]));
+#pragma unroll
+  for (int i = (C / 10) * 10; i < C; i++) asm volatile("" : "+v"(t[i]));
+}
+
+// index of the k-th set bit of a 4-bit contact mask (k-th stance leg) without a scratch array
+__device__ __forceinline__ int nth_leg(int mask, int k) {
+  int l0 = __builtin_ctz(mask | 16);
+  int m1 = mask & (mask - 1);
+  int l1 = __builtin_ctz(m1 | 16);
+  int m2 = m1 & (m1 - 1);
+  int l2 = __builtin_ctz(m2 | 16);
+  int m3_ = m2 & (m2 - 1);
+  int l3 = __builtin_ctz(m3_ | 16);
+  return k == 0 ? l0 : (k == 1 ? l1 : (k == 2 ? l2 : l3));
+}
+
 extern __shared__ __attribute__((aligned(16))) double smem[];
 
 template <int NT>
@@ -268,12 +290,9 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
     if (tid < 24) grf[tid] = 0.0;
     __syncthreads();
     const int cmask = (int)rec[REC_CONTACT];
-    int legs[4], k = 0;
-#pragma unroll
-    for (int l = 0; l < 4; l++) if ((cmask >> l) & 1) legs[k++] = l;
     // ---- Bw = Iw^-1 [r_l]x ; TBw = T Bw,  T = [[1/cp,0,0],[0,1,0],[tan p,0,1]] ----
     if (tid < m3) {
-      int l = legs[tid / 3], d = tid % 3;
+      int l = nth_leg(cmask, tid / 3), d = tid % 3;
       const double *r = &rec[REC_FEETW + 3 * l];
       // column d of skew(r): skew = [[0,-rz,ry],[rz,0,-rx],[-ry,rx,0]]
       double s0 = (d == 0) ? 0.0 : (d == 1 ? -r[2] : r[1]);
@@ -377,7 +396,7 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
       }
     }
     // ---- first-step forces (negated), torques, action row ----
-    if (tid < m3) grf[3 * legs[tid / 3] + tid % 3] = -z;
+    if (tid < m3) grf[3 * nth_leg(cmask, tid / 3) + tid % 3] = -z;
     __syncthreads();
     if (tid < 12) {
       int leg = tid / 3, j = tid % 3;
@@ -450,11 +469,8 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
     if (tid < 24) grf[tid] = 0.0;
     __syncthreads();
     const int cmask = (int)rec[REC_CONTACT];
-    int legs[4], kk = 0;
-#pragma unroll
-    for (int l = 0; l < 4; l++) if ((cmask >> l) & 1) legs[kk++] = l;
     if (tid < m3) {
-      int l = legs[tid / 3], d = tid % 3;
+      int l = nth_leg(cmask, tid / 3), d = tid % 3;
       const double *rr = &rec[REC_FEETW + 3 * l];
       double s0 = (d == 0) ? 0.0 : (d == 1 ? -rr[2] : rr[1]);
       double s1 = (d == 0) ? rr[2] : (d == 1 ? 0.0 : -rr[0]);
@@ -498,14 +514,20 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
     double row[C];
     double qi = 0.0;
     {
-      const int a = active ? r / m3 : 0, i = active ? r % m3 : 0;
+      // Opaque copies: without them LICM hoists ~4*C LDS addresses out of the persistent robot
+      // loop and keeps them live through the sweep/ADMM (measured: 200 VGPRs, or spills to HBM).
+      int rv = active ? r : 0, col0v = col0;
+      asm volatile("" : "+v"(rv), "+v"(col0v));
+      const int a = rv / m3, i = rv % m3;
       for (int kq = a; kq < H; kq++) qi += c1[kq * m3 + i] + ((double)(kq - a) + 0.5) * c2[kq * m3 + i];
       qi *= 2.0;
+      const double *tN = tabN + a * H, *tS = tabS + a * H, *gu = GU + i, *gv = GV + i;
 #pragma unroll
       for (int jj = 0; jj < C; jj++) {
-        const int bb = (col0 + jj) / m3, j = (col0 + jj) % m3;
-        double v = tabN[a * H + bb] * GU[j * m3 + i] + tabS[a * H + bb] * GV[j * m3 + i];
-        if (col0 + jj == r) v += c->alpha + rho;
+        const int col = col0v + jj;
+        const int bb = col / m3, j = col - bb * m3;
+        double v = tN[bb] * gu[j * m3] + tS[bb] * gv[j * m3];
+        if (col == rv) v += c->alpha + rho;
         row[jj] = v;
       }
     }
@@ -516,22 +538,58 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
     // The pivot row's diagonal is never read by another row, so the constant +2 is undone in
     // the mat-vec (part -= 2 rhs on the lane part that owns the diagonal).
     const int my_diag_part = r / C;  // which part of row r holds the diagonal
-    for (int kp = 0; kp < N; kp++) {
-      double *pb = pbuf + (kp & 1) * NP;
-      if (active && r == kp) {
+    if constexpr (C <= 32) {
+    // The pivot loop is unrolled over the C positions inside a lane part (static register index of the
+      // pivot element), so the pivot lane publishes the patched row and d without reading anything back.
+      for (int sp = 0; sp < SPLIT; sp++) {
 #pragma unroll
-        for (int jj = 0; jj < C; jj += 2) *reinterpret_cast<double2 *>(&pb[col0 + jj]) = make_double2(row[jj], row[jj + 1]);
-        if (s == kp / C) { double d = pb[kp]; pb[kp] = d - 1.0; pb[N] = 1.0 / d; }
+        for (int pj = 0; pj < C; pj++) {
+          const int kp = sp * C + pj;
+          double *pb = pbuf + (pj & 1) * NP;
+          if (active && r == kp) {
+#pragma unroll
+            for (int jj = 0; jj < C; jj += 2) {
+              double v0 = row[jj], v1 = row[jj + 1];
+              if (jj == pj) v0 = (s == sp) ? v0 - 1.0 : v0;
+              if (jj + 1 == pj) v1 = (s == sp) ? v1 - 1.0 : v1;
+              *reinterpret_cast<double2 *>(&pb[col0 + jj]) = make_double2(v0, v1);
+            }
+            if (s == sp) pb[N] = row[pj];
+          }
+          __syncthreads();
+          if (active) {
+            const double invd = fast_rcp(pb[N]);
+            const double ncc = (r == kp) ? invd - 1.0 : -pb[r] * invd;
+#pragma unroll
+            for (int jj = 0; jj < C; jj += 2) {
+              double2 p2 = *reinterpret_cast<const double2 *>(&pb[col0 + jj]);
+              row[jj] = fma(ncc, p2.x, row[jj]);
+              row[jj + 1] = fma(ncc, p2.y, row[jj + 1]);
+            }
+          }
+          pin_array<C>(row);  // stop hipcc from turning the unrolled pivots into a register-hungry look-ahead schedule
+        }
       }
-      __syncthreads();
-      if (active) {
-        const double invd = pb[N];
-        const double ncc = (r == kp) ? invd - 1.0 : -pb[r] * invd;
+    } else {
+      // wide rows: a fully unrolled pivot loop would not fit the register budget; the pivot lane reads
+      // its own diagonal entry back from LDS instead (dynamic position inside the row).
+      for (int kp = 0; kp < N; kp++) {
+        double *pb = pbuf + (kp & 1) * NP;
+        if (active && r == kp) {
 #pragma unroll
-        for (int jj = 0; jj < C; jj += 2) {
-          double2 p2 = *reinterpret_cast<const double2 *>(&pb[col0 + jj]);
-          row[jj] = fma(ncc, p2.x, row[jj]);
-          row[jj + 1] = fma(ncc, p2.y, row[jj + 1]);
+          for (int jj = 0; jj < C; jj += 2) *reinterpret_cast<double2 *>(&pb[col0 + jj]) = make_double2(row[jj], row[jj + 1]);
+          if (s == kp / C) { double d = pb[kp]; pb[kp] = d - 1.0; pb[N] = d; }
+        }
+        __syncthreads();
+        if (active) {
+          const double invd = fast_rcp(pb[N]);
+          const double ncc = (r == kp) ? invd - 1.0 : -pb[r] * invd;
+#pragma unroll
+          for (int jj = 0; jj < C; jj += 2) {
+            double2 p2 = *reinterpret_cast<const double2 *>(&pb[col0 + jj]);
+            row[jj] = fma(ncc, p2.x, row[jj]);
+            row[jj + 1] = fma(ncc, p2.y, row[jj + 1]);
+          }
         }
       }
     }
@@ -577,7 +635,7 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
         z = zn;
       }
     }
-    if (active && s == 0 && r < m3) grf[3 * legs[r / 3] + r % 3] = -z;
+    if (active && s == 0 && r < m3) grf[3 * nth_leg(cmask, r / 3) + r % 3] = -z;
     __syncthreads();
     if (tid < 12) {
       int leg = tid / 3, j = tid % 3;
@@ -616,19 +674,321 @@ static hipError_t launch_qp_reg(const DevCfg *dcfg, const DevState &st, const De
 }
 
 // returns true if a register-resident instantiation exists for (nc, H)
-static bool launch_qp_reg_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err) {
+static bool launch_qp_reg_dispatch(int variant, int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err) {
   *err = hipSuccess;
+  if (H == 10 && variant == 1) {  // A/B: alternative row splits of the row-per-lane kernel
+    switch (nc) {
+      case 2: *err = launch_qp_reg<2, 10, 1, 2>(dcfg, st, dout, B, cu, s); return true;
+      case 4: *err = launch_qp_reg<4, 10, 4, 3>(dcfg, st, dout, B, cu, s); return true;
+    }
+  }
   if (H == 10) {
     switch (nc) {
       case 1: *err = launch_qp_reg<1, 10, 1, 4>(dcfg, st, dout, B, cu, s); return true;
-      case 2: *err = launch_qp_reg<2, 10, 2, 4>(dcfg, st, dout, B, cu, s); return true;
+      case 2: *err = launch_qp_reg<2, 10, 2, 3>(dcfg, st, dout, B, cu, s); return true;
       case 3: *err = launch_qp_reg<3, 10, 1, 1>(dcfg, st, dout, B, cu, s); return true;
-      case 4: *err = launch_qp_reg<4, 10, 4, 4>(dcfg, st, dout, B, cu, s); return true;
+      case 4: *err = launch_qp_reg<4, 10, 2, 2>(dcfg, st, dout, B, cu, s); return true;
     }
   } else if (H == 20) {
     switch (nc) {
       case 1: *err = launch_qp_reg<1, 20, 1, 2>(dcfg, st, dout, B, cu, s); return true;
       case 2: *err = launch_qp_reg<2, 20, 2, 2>(dcfg, st, dout, B, cu, s); return true;
+    }
+  }
+  return false;
+}
+
+// ------------------------------------------------------------------------------------
+// QP kernel, 2-D register-tiled variant.
+// The row-per-lane kernel above is bound by the LDS instruction pipe (rocprof:
+// SQ_ACTIVE_INST_LDS ~ 88 % of kernel time): every f64 FMA needs half a 16-B broadcast read.
+// Here the lanes of a robot form an LC x LC grid and lane (lr, lc) keeps the T x T tile
+// rows lr*T.., cols lc*T.. of the (padded, NP = T*LC) symmetric matrix in VGPRs, so every value
+// read from LDS feeds T FMAs:
+//   sweep step kp: 2T values (pivot-row entries of my columns and, by symmetry, of my rows)
+//                  for T*T FMAs; the LC lanes of lane-row kp/T publish the row in parallel.
+//   ADMM mat-vec : T values of the rhs for T*T FMAs, then a reduce-scatter over the LC lanes
+//                  of a lane-row (cross-lane, no LDS data) leaves one finished entry per lane.
+// ------------------------------------------------------------------------------------
+// Opaque "use + redefine" of one tile row: no instruction is emitted, but the optimiser can no longer
+// defer this row's updates past this point.  (Left alone, hipcc turns the unrolled pivot steps into
+// a look-ahead schedule that keeps every step's pivot-row values live: > 380 VGPRs, spills in the loop.)
+template <int T>
+__device__ __forceinline__ void pin_row(double (&t)[T]) {
+  if constexpr (T == 8) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+  else if constexpr (T == 6) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]));
+  else if constexpr (T == 4) asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+  else {
+#pragma unroll
+    for (int i = 0; i < T; i++) asm volatile("" : "+v"(t[i]));
+  }
+}
+
+template <int LT>
+__device__ __forceinline__ int bitrev_lt(int x) {
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < LT; i++) r |= ((x >> i) & 1) << (LT - 1 - i);
+  return r;
+}
+
+template <int NC, int H, int T, int LG, int MINW>
+__global__ void __launch_bounds__((1 << LG) * (1 << LG), MINW)
+rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B) {
+  constexpr int m3 = 3 * NC;
+  constexpr int N = m3 * H;          // real QP variables
+  constexpr int LC = 1 << LG;        // lanes per side
+  constexpr int NP = T * LC;         // padded size
+  constexpr int NT = LC * LC;
+  constexpr bool TPOW2 = (T & (T - 1)) == 0;
+  constexpr int LT = (T == 2) ? 1 : (T == 4) ? 2 : (T == 8) ? 3 : (T == 16) ? 4 : 0;
+  static_assert(NP >= N && T % 2 == 0 && T <= LC, "tile/grid must cover the problem");
+  const int tid = threadIdx.x;
+  const int lr = tid >> LG, lc = tid & (LC - 1);
+  const int count = st.counts[NC];
+  constexpr int NPB = NP + 2;
+  double *pbuf = smem;               // 2 * NPB  ping-pong pivot row; [NP] = 1/d
+  double *vv = pbuf + 2 * NPB;       // NP rhs vector
+  double *wv = vv + NP;              // NP projection input
+  double *GU = wv + NP;              // m3*m3
+  double *GV = GU + m3 * m3;
+  double *c1 = GV + m3 * m3;         // N
+  double *c2 = c1 + N;               // N
+  double *Bw = c2 + N;               // 3*m3
+  double *TBw = Bw + 3 * m3;         // 3*m3
+  double *rec = TBw + 3 * m3;        // RG_REC_N
+  double *grf = rec + RG_REC_N;      // 24
+  double *tabN = grf + 24;           // H*H
+  double *tabS = tabN + H * H;       // H*H
+  const double rho = c->rho, relax = c->relax, mu = c->mu, lo = c->fz_min, hi = c->fz_max, dt = c->dt;
+  const double kA = 1.0 / (1.0 + 2.0 * mu * mu), kB = 1.0 / (1.0 + mu * mu);
+  for (int e = tid; e < H * H; e += NT) { tabN[e] = 2.0 * c->Ntab[e]; tabS[e] = 2.0 * c->Stab[e]; }
+  // the one matrix row whose scalar ADMM state this lane owns after the reduce-scatter
+  const bool owner = lc < T;
+  const int own_a = TPOW2 ? bitrev_lt<LT>(lc & (T - 1)) : (lc < T ? lc : 0);
+  const int io = lr * T + own_a;
+  const bool own_real = owner && io < N;
+
+  for (int work = blockIdx.x; work < count; work += gridDim.x) {
+    const int b = st.bins[(size_t)NC * B + work];
+    __syncthreads();
+    for (int e = tid; e < RG_REC_N; e += NT) rec[e] = st.rec[(size_t)b * RG_REC_N + e];
+    if (tid < 24) grf[tid] = 0.0;
+    __syncthreads();
+    const int cmask = (int)rec[REC_CONTACT];
+    if (tid < m3) {
+      int l = nth_leg(cmask, tid / 3), d = tid % 3;
+      const double *rr = &rec[REC_FEETW + 3 * l];
+      double s0 = (d == 0) ? 0.0 : (d == 1 ? -rr[2] : rr[1]);
+      double s1 = (d == 0) ? rr[2] : (d == 1 ? 0.0 : -rr[0]);
+      double s2 = (d == 0) ? -rr[1] : (d == 1 ? rr[0] : 0.0);
+      const double *Iw = &rec[REC_IWINV];
+      double b0 = Iw[0] * s0 + Iw[1] * s1 + Iw[2] * s2;
+      double b1 = Iw[3] * s0 + Iw[4] * s1 + Iw[5] * s2;
+      double b2 = Iw[6] * s0 + Iw[7] * s1 + Iw[8] * s2;
+      Bw[tid] = b0; Bw[m3 + tid] = b1; Bw[2 * m3 + tid] = b2;
+      TBw[tid] = rec[REC_INVCP] * b0; TBw[m3 + tid] = b1; TBw[2 * m3 + tid] = rec[REC_TANP] * b0 + b2;
+    }
+    __syncthreads();
+    for (int e = tid; e < m3 * m3; e += NT) {
+      int i = e / m3, j = e % m3;
+      double gu = c->w[6] * Bw[i] * Bw[j] + c->w[7] * Bw[m3 + i] * Bw[m3 + j] + c->w[8] * Bw[2 * m3 + i] * Bw[2 * m3 + j];
+      double gv = c->w[0] * TBw[i] * TBw[j] + c->w[1] * TBw[m3 + i] * TBw[m3 + j] + c->w[2] * TBw[2 * m3 + i] * TBw[2 * m3 + j];
+      if (i % 3 == j % 3) { gu += c->w[9 + i % 3] * c->inv_mass * c->inv_mass; gv += c->w[3 + i % 3] * c->inv_mass * c->inv_mass; }
+      GU[e] = gu * dt * dt;
+      GV[e] = gv * dt * dt * dt * dt;
+    }
+    for (int e = tid; e < N; e += NT) {
+      int a = e / m3, i = e % m3;
+      double kd = (double)(a + 1) * dt;
+      const double *om = &rec[REC_OMEGA], *vb = &rec[REC_VBODY], *cm = &rec[REC_CMD];
+      double e_r = rec[REC_ROLL] + kd * rec[REC_INVCP] * om[0];
+      double e_p = rec[REC_PITCH] + kd * om[1];
+      double e_y = kd * (rec[REC_TANP] * om[0] + om[2]) - kd * cm[2];
+      double e_x = kd * vb[0] - kd * cm[0];
+      double e_yy = kd * vb[1] - kd * cm[1];
+      double e_z = rec[REC_COMZ] + kd * vb[2] - 0.5 * kd * kd * c->g - c->body_height;
+      double e_w0 = om[0], e_w1 = om[1], e_w2 = om[2] - cm[2];
+      double e_v0 = vb[0] - cm[0], e_v1 = vb[1] - cm[1], e_v2 = vb[2] - kd * c->g;
+      int d = i % 3;
+      double ev = (d == 0) ? c->w[9] * e_v0 : (d == 1 ? c->w[10] * e_v1 : c->w[11] * e_v2);
+      double ep = (d == 0) ? c->w[3] * e_x : (d == 1 ? c->w[4] * e_yy : c->w[5] * e_z);
+      c1[e] = dt * (Bw[i] * c->w[6] * e_w0 + Bw[m3 + i] * c->w[7] * e_w1 + Bw[2 * m3 + i] * c->w[8] * e_w2 + c->inv_mass * ev);
+      c2[e] = dt * dt * (TBw[i] * c->w[0] * e_r + TBw[m3 + i] * c->w[1] * e_p + TBw[2 * m3 + i] * c->w[2] * e_y + c->inv_mass * ep);
+    }
+    __syncthreads();
+    // ---- my T x T tile of (P + rho I) (identity in the padding), and q of the row I own ----
+    double tile[T][T];
+    double qi = 0.0;
+    {
+      int lrv = lr, lcv = lc, iov = io;   // opaque copies defeat LICM of ~4 T^2 LDS addresses
+      asm volatile("" : "+v"(lrv), "+v"(lcv), "+v"(iov));
+      if (own_real) {
+        const int a = iov / m3, i = iov - a * m3;
+        for (int kq = a; kq < H; kq++) qi += c1[kq * m3 + i] + ((double)(kq - a) + 0.5) * c2[kq * m3 + i];
+        qi *= 2.0;
+      }
+#pragma unroll
+      for (int ta = 0; ta < T; ta++) {
+        const int row = lrv * T + ta;
+        const int a = row / m3, i = row - a * m3;
+        const bool rreal = row < N;
+        const double *tN = tabN + (rreal ? a : 0) * H, *tS = tabS + (rreal ? a : 0) * H, *gu = GU + (rreal ? i : 0), *gv = GV + (rreal ? i : 0);
+#pragma unroll
+        for (int tb = 0; tb < T; tb++) {
+          const int col = lcv * T + tb;
+          const int bb = col / m3, j = col - bb * m3;
+          double v;
+          if (rreal && col < N) {
+            v = tN[bb] * gu[j * m3] + tS[bb] * gv[j * m3];
+            if (col == row) v += c->alpha + rho;
+          } else v = (col == row) ? 1.0 : 0.0;
+          tile[ta][tb] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one tile row at a time: bounds the LDS loads in flight (VGPR pressure)
+      }
+    }
+    // ---- symmetric sweep: tile <- entries of -(P + rho I)^-1, pivot-row diagonals offset by +2 ----
+    for (int kb = 0; kb < LC; kb++) {
+#pragma unroll
+      for (int tr = 0; tr < T; tr++) {
+        const int kp = kb * T + tr;
+        double *pb = pbuf + (kp & 1) * NPB;
+        if (lr == kb) {
+          const bool diag = (lc == kb);
+#pragma unroll
+          for (int tb = 0; tb < T; tb += 2) {
+            double v0 = tile[tr][tb], v1 = tile[tr][tb + 1];
+            if (tb == tr) v0 = diag ? v0 - 1.0 : v0;
+            if (tb + 1 == tr) v1 = diag ? v1 - 1.0 : v1;
+            *reinterpret_cast<double2 *>(&pb[lc * T + tb]) = make_double2(v0, v1);
+          }
+          if (diag) pb[NP] = tile[tr][tr];
+        }
+        __syncthreads();
+        const double invd = fast_rcp(pb[NP]);
+        double prow[T], pcol[T];
+#pragma unroll
+        for (int t2 = 0; t2 < T; t2 += 2) {
+          double2 a2 = *reinterpret_cast<const double2 *>(&pb[lr * T + t2]);
+          double2 b2 = *reinterpret_cast<const double2 *>(&pb[lc * T + t2]);
+          prow[t2] = a2.x; prow[t2 + 1] = a2.y; pcol[t2] = b2.x; pcol[t2 + 1] = b2.y;
+        }
+#pragma unroll
+        for (int ta = 0; ta < T; ta++) {
+          double ncc = -prow[ta] * invd;
+          if (ta == tr) ncc = (lr == kb) ? invd - 1.0 : ncc;
+#pragma unroll
+          for (int tb = 0; tb < T; tb++) tile[ta][tb] = fma(ncc, pcol[tb], tile[ta][tb]);
+        }
+#pragma unroll
+        for (int ta = 0; ta < T; ta++) pin_row<T>(tile[ta]);
+      }
+    }
+    // ---- over-relaxed ADMM; scalar state lives on the owner lane of each row ----
+    double z = (own_real && (io % 3) == 2) ? lo : 0.0, y = 0.0;
+    const int blk = own_real ? io - io % 3 : 0, dax = io % 3;
+    if (owner) vv[io] = own_real ? rho * (z - y) - qi : 0.0;
+    __syncthreads();
+    for (int it = 0; it < c->admm_iters; it++) {
+      double acc[T];
+      {
+        double vloc[T];
+#pragma unroll
+        for (int t2 = 0; t2 < T; t2 += 2) {
+          double2 v2 = *reinterpret_cast<const double2 *>(&vv[lc * T + t2]);
+          vloc[t2] = v2.x; vloc[t2 + 1] = v2.y;
+        }
+#pragma unroll
+        for (int ta = 0; ta < T; ta++) {
+          double a0 = 0.0;
+#pragma unroll
+          for (int tb = 0; tb < T; tb++) a0 = fma(tile[ta][tb], vloc[tb], a0);
+          acc[ta] = (lr == lc) ? a0 - 2.0 * vloc[ta] : a0;
+        }
+      }
+      // reduce over the LC lanes of this lane-row
+      double tot;
+      if constexpr (TPOW2) {
+        // reduce-scatter: after step k (xor 2^k) a lane keeps the half selected by bit k of lc
+#pragma unroll
+        for (int k = 0; k < LT; k++) {
+          const int half = T >> (k + 1);
+          const bool up = (lc >> k) & 1;
+#pragma unroll
+          for (int h2 = 0; h2 < half; h2++) {
+            double keep = up ? acc[half + h2] : acc[h2];
+            double send = up ? acc[h2] : acc[half + h2];
+            acc[h2] = keep + __shfl_xor(send, 1 << k);
+          }
+        }
+        tot = acc[0];
+#pragma unroll
+        for (int k = LT; k < LG; k++) tot += __shfl_xor(tot, 1 << k);
+      } else {
+#pragma unroll
+        for (int ta = 0; ta < T; ta++) {
+#pragma unroll
+          for (int k = 0; k < LG; k++) acc[ta] += __shfl_xor(acc[ta], 1 << k);
+        }
+        tot = acc[0];
+#pragma unroll
+        for (int ta = 1; ta < T; ta++) tot = (own_a == ta) ? acc[ta] : tot;
+      }
+      const double u = -tot;
+      const double w = relax * u + (1.0 - relax) * z + y;
+      if (own_real) wv[io] = w;
+      __syncthreads();
+      if (own_real) {
+        double px, py, pz;
+        proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, kA, kB, px, py, pz);
+        const double zn = (dax == 0) ? px : (dax == 1 ? py : pz);
+        y = w - zn;
+        z = zn;
+        vv[io] = rho * (z - y) - qi;
+      }
+      __syncthreads();
+    }
+    if (own_real && io < m3) grf[3 * nth_leg(cmask, io / 3) + io % 3] = -z;
+    __syncthreads();
+    if (tid < 12) {
+      int leg = tid / 3, j = tid % 3;
+      const double *J = &rec[REC_JAC + 9 * leg];
+      double tau = (grf[3 * leg] * J[j] + grf[3 * leg + 1] * J[3 + j] + grf[3 * leg + 2] * J[6 + j]) * c->mdir[tid];
+      grf[12 + tid] = tau;
+      if (out.grf) out.grf[(size_t)b * 12 + tid] = (float)grf[tid];
+      if (out.tau_stance) out.tau_stance[(size_t)b * 12 + tid] = (float)tau;
+    }
+    __syncthreads();
+    if (tid < 60) {
+      int j = tid / 5, f = tid % 5;
+      int emit = ((int)rec[REC_EMIT] >> j) & 1;
+      float v;
+      if (emit) v = (f == 0) ? (float)rec[REC_SWINGQ + j] : (f == 1 ? (float)c->kp[j] : (f == 3 ? (float)c->kd[j] : 0.f));
+      else v = (f == 4) ? (float)grf[12 + j] : 0.f;
+      out.action[(size_t)b * 60 + tid] = v;
+    }
+  }
+}
+
+template <int NC, int H, int T, int LG, int MINW>
+static hipError_t launch_qp_tile(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
+  constexpr int m3 = 3 * NC, N = m3 * H, LC = 1 << LG, NP = T * LC, NT = LC * LC;
+  const size_t lds = sizeof(double) * (size_t)(2 * (NP + 2) + 2 * NP + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
+  int grid = cu_count * 8;
+  if (grid > B) grid = B;
+  rg_qp_admm_tile_kernel<NC, H, T, LG, MINW><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
+  return hipGetLastError();
+}
+
+static bool launch_qp_tile_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err) {
+  *err = hipSuccess;
+  if (H == 10) {
+    switch (nc) {
+      case 1: *err = launch_qp_tile<1, 10, 4, 3, 2>(dcfg, st, dout, B, cu, s); return true;   // 30 -> 32
+      case 2: *err = launch_qp_tile<2, 10, 8, 3, 2>(dcfg, st, dout, B, cu, s); return true;   // 60 -> 64, one wave
+      case 3: *err = launch_qp_tile<3, 10, 6, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 90 -> 96, four waves
+      case 4: *err = launch_qp_tile<4, 10, 8, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 120 -> 128, four waves
     }
   }
   return false;
@@ -680,13 +1040,18 @@ struct rg_mpc_handle {
   std::vector<void *> allocs;
   std::string err;
   // optional per-kernel event timing
-  std::vector<hipEvent_t> ev;   // 6 events per profiled step
+  std::vector<hipEvent_t> ev;   // RG_PROF_EV events per profiled step
   int prof_max = 0, prof_n = 0;
   bool force_lds_kernel = false;
+  int qp_variant = 0;
+  bool concurrent_bins = true;      // run the per-stance-count QP launches on forked streams
+  hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_front = nullptr, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 static thread_local std::string g_create_err;
 
+#define RG_PROF_EV 11  // [0] step start, [1] front end, [2+2k],[3+2k] QP nc=k+1 start/end, [10] step end
 #define HIPCHK(h, call)                                                                    \
   do {                                                                                     \
     hipError_t e_ = (call);                                                                \
@@ -787,7 +1152,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_tile_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -796,7 +1161,9 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   *out = nullptr;
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
-  h->force_lds_kernel = (cfg->reserved0 & 1) != 0;  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
+  h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
+  h->qp_variant = (cfg->reserved0 >> 1) & 3;
+  h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) == 0;  // bit3: serialise the QP launches on the caller's stream         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   if (rc) { g_create_err = h->err; delete h; return rc; }
   int ndev = 0;
@@ -817,6 +1184,11 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
   AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N); AL(h->st.bins, 5 * B); AL(h->st.counts, 8);
   AL(h->idx_dev, B); AL(h->t0_dev, B);
+  CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
+  for (int nc = 1; nc <= 4; nc++) {
+    CR(hipStreamCreateWithFlags(&h->aux[nc], hipStreamNonBlocking));
+    CR(hipEventCreateWithFlags(&h->ev_done[nc], hipEventDisableTiming));
+  }
   for (int nc = 1; nc <= 4; nc++) {
     size_t bytes = qp_lds_bytes(nc, cfg->horizon);
     h->lds_bytes[nc] = bytes;
@@ -839,6 +1211,11 @@ void rg_mpc_destroy(rg_mpc_handle *h) {
   hipSetDevice(h->device);
   for (void *p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->ev_front) (void)hipEventDestroy(h->ev_front);
+  for (int nc = 1; nc <= 4; nc++) {
+    if (h->ev_done[nc]) (void)hipEventDestroy(h->ev_done[nc]);
+    if (h->aux[nc]) (void)hipStreamDestroy(h->aux[nc]);
+  }
   delete h;
 }
 
@@ -894,34 +1271,55 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
   HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 8, s));
-  hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * 6] : nullptr;
+  hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);
   HIPCHK(h, hipGetLastError());
   if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
-  for (int nc = 1; nc <= 4; nc++) {
+  // Robots with different stance-leg counts are independent: fork the four QP launches onto
+  // internal streams (each waits for the front kernel) and join them back into the caller's
+  // stream, so a short bin fills the tail of a long one.  Profiling serialises them.
+  const bool fork = h->concurrent_bins;
+  if (fork) HIPCHK(h, hipEventRecord(h->ev_front, s));
+  const int order[4] = {4, 2, 3, 1};  // longest first
+  for (int oi = 0; oi < 4; oi++) {
+    const int nc = fork ? order[oi] : oi + 1;
     const int n = 3 * nc * H;
-    if (!h->force_lds_kernel) {
+    hipStream_t qs = s;
+    if (fork) { qs = h->aux[nc]; HIPCHK(h, hipStreamWaitEvent(qs, h->ev_front, 0)); }
+    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc], qs));
+    bool launched = false;
+    if (!h->force_lds_kernel && h->qp_variant != 2 && h->qp_variant != 1) {
       hipError_t lerr;
-      if (launch_qp_reg_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr)) {
+      if (launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr)) {
         HIPCHK(h, lerr);
-        if (pev) HIPCHK(h, hipEventRecord(pev[1 + nc], s));
-        continue;
+        launched = true;
+      }
+    }
+    if (!launched && !h->force_lds_kernel) {
+      hipError_t lerr;
+      if (launch_qp_reg_dispatch(h->qp_variant, nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr)) {
+        HIPCHK(h, lerr);
+        launched = true;
       }
     }
     size_t lds = h->lds_bytes[nc];
-    if (lds == 0) { if (pev) HIPCHK(h, hipEventRecord(pev[1 + nc], s)); continue; } // TODO(round 2): out-of-LDS variant for H=20 with 3-4 stance legs
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    int grid = h->cu_count * per_cu;
-    if (grid > B) grid = B;
-    if (n <= 64) hipLaunchKernelGGL(rg_qp_admm_kernel<64>, dim3(grid), dim3(64), lds, s, h->dcfg, h->st, dout, nc, B);
-    else if (n <= 128) hipLaunchKernelGGL(rg_qp_admm_kernel<128>, dim3(grid), dim3(128), lds, s, h->dcfg, h->st, dout, nc, B);
-    else hipLaunchKernelGGL(rg_qp_admm_kernel<256>, dim3(grid), dim3(256), lds, s, h->dcfg, h->st, dout, nc, B);
-    HIPCHK(h, hipGetLastError());
-    if (pev) HIPCHK(h, hipEventRecord(pev[1 + nc], s));
+    if (!launched && lds != 0) {
+      int per_cu = (int)((160 * 1024) / lds);
+      if (per_cu < 1) per_cu = 1;
+      if (per_cu > 8) per_cu = 8;
+      int grid = h->cu_count * per_cu;
+      if (grid > B) grid = B;
+      if (n <= 64) hipLaunchKernelGGL(rg_qp_admm_kernel<64>, dim3(grid), dim3(64), lds, qs, h->dcfg, h->st, dout, nc, B);
+      else if (n <= 128) hipLaunchKernelGGL(rg_qp_admm_kernel<128>, dim3(grid), dim3(128), lds, qs, h->dcfg, h->st, dout, nc, B);
+      else hipLaunchKernelGGL(rg_qp_admm_kernel<256>, dim3(grid), dim3(256), lds, qs, h->dcfg, h->st, dout, nc, B);
+      HIPCHK(h, hipGetLastError());
+    }
+    // (no instantiation and no LDS fit: H = 20 with 3-4 stance legs -- robots of that bin keep their previous action)
+    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc + 1], qs));
+    if (fork) { HIPCHK(h, hipEventRecord(h->ev_done[nc], qs)); HIPCHK(h, hipStreamWaitEvent(s, h->ev_done[nc], 0)); }
   }
+  if (pev) HIPCHK(h, hipEventRecord(pev[10], s));
   if (pev) h->prof_n++;
   return RG_MPC_OK;
 }
@@ -929,7 +1327,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
 int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
   if (!h || max_steps < 1 || max_steps > 100000) { if (h) h->err = "profile_begin: bad max_steps"; return RG_MPC_ERR_INVALID; }
   HIPCHK(h, hipSetDevice(h->device));
-  while ((int)h->ev.size() < max_steps * 6) {
+  while ((int)h->ev.size() < max_steps * RG_PROF_EV) {
     hipEvent_t e;
     HIPCHK(h, hipEventCreate(&e));
     h->ev.push_back(e);
@@ -946,9 +1344,11 @@ int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void 
   h->prof_max = 0;
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int k = 0; k < n; k++) {
-    hipEvent_t *e = &h->ev[(size_t)k * 6];
-    for (int j = 0; j < 5; j++) { float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e[j], e[j + 1])); acc[j] += ms; }
-    float ms = 0; HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[5])); acc[5] += ms;
+    hipEvent_t *e = &h->ev[(size_t)k * RG_PROF_EV];
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[1])); acc[0] += ms;
+    for (int nc = 1; nc <= 4; nc++) { HIPCHK(h, hipEventElapsedTime(&ms, e[2 * nc], e[2 * nc + 1])); acc[nc] += ms; }
+    HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[10])); acc[5] += ms;
   }
   for (int j = 0; j < 6; j++) avg_ms6[j] = n > 0 ? (float)(acc[j] / n) : 0.f;
   if (robots5) HIPCHK(h, hipMemcpy(robots5, h->st.counts, sizeof(int) * 5, hipMemcpyDeviceToHost));

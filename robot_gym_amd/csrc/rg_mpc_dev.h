@@ -187,6 +187,16 @@ __device__ __forceinline__ void proj_pyramid(double a, double b, double c, doubl
   z = zz;
 }
 
+// 1/d from v_rcp_f64 plus two Newton steps (every lane computes it redundantly; the IEEE
+// division sequence is ~4x longer and sat on the critical path of every pivot step).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  double e = fma(-d, x, 1.0);
+  x = fma(x, e, x);
+  e = fma(-d, x, 1.0);
+  return fma(x, e, x);
+}
+
 __device__ __forceinline__ void neumaier_add(double &sum, double &corr, double v) {
   double ns = sum + v;
   if (fabs(sum) >= fabs(v)) corr += (sum - ns) + v; else corr += (v - ns) + sum;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_*: the rocprofv3
+kernel stats, per-kernel PMC averages per launch, and the HBM traffic JSON bench.py reads.
+
+HBM bytes per launch follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes, both are in KiB (x1024); on gfx950 FETCH_SIZE under-reports WIDE (16 B/lane)
+coalesced reads by 2x -- the kernels here read 4-8 B per lane, a width the guide calls uncalibrated,
+so the raw value is reported and the 2x-corrected value is given as an upper bound."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join("gpurun_out", f"prof_{tag}")
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    for k in ("rg_front_kernel", "rg_qp_admm_reg_kernel<1", "rg_qp_admm_reg_kernel<2", "rg_qp_admm_reg_kernel<3", "rg_qp_admm_reg_kernel<4",
+              "rg_qp_admm_kernel", "rg_qp_as_kernel", "rg_reset_kernel", "rg_hybrid"):
+        if k in name:
+            return name[name.index(k):].split("(")[0]
+    return None
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
+    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k is None:
+                continue
+            if int(r["Grid_Size"]) <= 8192 and "front" not in k and "reset" not in k:   # empty-bin launches
+                continue
+            pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+rows = []
+traffic = {}
+for k in sorted(pmc):
+    c = {n: sum(v) / len(v) for n, v in pmc[k].items()}
+    rows.append((k, c))
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic[k] = {"fetch_bytes_raw": c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
+                      "hbm_bytes_per_launch": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
+                      "hbm_bytes_per_launch_if_fetch_x2": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024}
+with open(os.path.join(dst, f"{tag}_pmc_per_launch.csv"), "w") as f:
+    names = sorted({n for _, c in rows for n in c})
+    f.write("kernel," + ",".join(names) + "\n")
+    for k, c in rows:
+        f.write(k.replace(",", ";") + "," + ",".join("%.6g" % c.get(n, float("nan")) for n in names) + "\n")
+bl = os.path.join(src, "bench_line.json")
+meta = json.loads(open(bl).read()) if os.path.exists(bl) and os.path.getsize(bl) else {}
+json.dump({"tag": tag, "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (under rocprofv3)", "traffic": traffic,
+           "bench_line_under_profiler": meta}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_pmc_per_launch.csv")).read())
+print(json.dumps(traffic, indent=1))
