@@ -990,6 +990,13 @@ static bool launch_qp_tile_dispatch(int nc, int H, const DevCfg *dcfg, const Dev
       case 3: *err = launch_qp_tile<3, 10, 6, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 90 -> 96, four waves
       case 4: *err = launch_qp_tile<4, 10, 8, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 120 -> 128, four waves
     }
+  } else if (H == 20) {
+    switch (nc) {
+      case 1: *err = launch_qp_tile<1, 20, 8, 3, 2>(dcfg, st, dout, B, cu, s); return true;   // 60 -> 64
+      case 2: *err = launch_qp_tile<2, 20, 8, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 120 -> 128
+      case 3: *err = launch_qp_tile<3, 20, 6, 5, 1>(dcfg, st, dout, B, cu, s); return true;   // 180 -> 192, sixteen waves
+      case 4: *err = launch_qp_tile<4, 20, 8, 5, 1>(dcfg, st, dout, B, cu, s); return true;   // 240 -> 256, sixteen waves
+    }
   }
   return false;
 }
@@ -1044,7 +1051,7 @@ struct rg_mpc_handle {
   int prof_max = 0, prof_n = 0;
   bool force_lds_kernel = false;
   int qp_variant = 0;
-  bool concurrent_bins = true;      // run the per-stance-count QP launches on forked streams
+  bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_front = nullptr, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -1163,7 +1170,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   h->cfg = *cfg; h->B = batch; h->device = device;
   h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
-  h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) == 0;  // bit3: serialise the QP launches on the caller's stream         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
+  h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   if (rc) { g_create_err = h->err; delete h; return rc; }
   int ndev = 0;
@@ -1276,9 +1283,9 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   hipLaunchKernelGGL(rg_front_kernel, dim3((B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);
   HIPCHK(h, hipGetLastError());
   if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
-  // Robots with different stance-leg counts are independent: fork the four QP launches onto
-  // internal streams (each waits for the front kernel) and join them back into the caller's
-  // stream, so a short bin fills the tail of a long one.  Profiling serialises them.
+  // Robots with different stance-leg counts are independent; optionally (reserved0 bit3) the four QP
+  // launches are forked onto internal streams and joined back into the caller's stream.  Measured
+  // on MI355X this is ~8 % slower than back-to-back launches, so it is off by default.
   const bool fork = h->concurrent_bins;
   if (fork) HIPCHK(h, hipEventRecord(h->ev_front, s));
   const int order[4] = {4, 2, 3, 1};  // longest first

@@ -50,3 +50,28 @@ def test_kinematics_on_device(oracle_lib):
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=20)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=20)
     _check(gpu, orc)
+
+
+def test_config5_horizon_20(oracle_lib):
+    """BASELINE config 5 shape: horizon 20 (n = 120 in trot, 240 in double support).  The contact
+    flags stay constant over the horizon (upstream behaviour); the per-step contact schedule of
+    config 5 is an extension that is not built."""
+    cfg = MPCConfig.for_robot("ghost", horizon=20, admm_iters=200)
+    state, cmd, t_off = synthetic.make_states(96, cfg, seed=6)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    _check(gpu, orc)
+    bins = np.array([g["bins"] for g in gpu])
+    assert bins[:, 2].sum() > 0 and bins[:, 4].sum() > 0
+
+
+def test_three_leg_stance_gait(oracle_lib):
+    """A walking gait (duty 0.75, legs a quarter cycle apart): exercises the 3- and 4-stance-leg QP kernels."""
+    cfg = MPCConfig.for_robot("ghost", duty_factor=(0.75,) * 4, stance_duration=(0.3,) * 4,
+                              init_phase=(0.0, 0.5, 0.25, 0.75), init_state=(1, 1, 1, 1))
+    state, cmd, t_off = synthetic.make_states(96, cfg, seed=7)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=12, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=12, jitter=0.1)
+    _check(gpu, orc)
+    bins = np.array([g["bins"] for g in gpu])
+    assert bins[:, 3].sum() > 0
