@@ -39,58 +39,61 @@ __device__ inline void gait_leg(const DevCfg *c, int leg, double t, int contact,
   }
 }
 
-__global__ void __launch_bounds__(64)
+// One lane per (robot, leg): the four lanes of a quad share a robot.  Per-leg work (gait state, swing
+// target / trajectory / IK, FK, lever arms) runs in parallel; per-robot values are combined with
+// quad ballots/shuffles and written by the leg-0 lane.  (A lane-per-robot version left 4096 robots
+// on 64 waves with a ~290k-cycle serial chain each.)
+__global__ void __launch_bounds__(256)
 rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out, double t_now, int B) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = gid >> 2, leg = gid & 3;
+  if (b >= B) return;  // B*4 is padded to whole quads by construction (4 lanes per robot)
+  const int lane = threadIdx.x & 63, qbase = lane & ~3;
   const int W = c->window;
-  // ---- inputs (component-major, coalesced over robots) ----
-  double rpy[3], rate[3], vw[3], quat[4], q[12], cmd[3];
-  int contact[4];
+  // ---- inputs ----
+  double rpy[3], rate[3], vw[3], quat[4], q3[3], cmd[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) { rpy[i] = in.rpy[i * B + b]; rate[i] = in.rpy_rate[i * B + b]; vw[i] = in.v_world[i * B + b]; }
 #pragma unroll
-  for (int i = 0; i < 4; i++) { quat[i] = in.quat[i * B + b]; contact[i] = in.contact[i * B + b]; }
+  for (int i = 0; i < 4; i++) quat[i] = in.quat[i * B + b];
 #pragma unroll
-  for (int i = 0; i < 12; i++) q[i] = in.q[i * B + b];
+  for (int i = 0; i < 3; i++) q3[i] = in.q[(3 * leg + i) * B + b];
+  const int contact = in.contact[leg * B + b];
   const float *cmdp = in.cmd ? in.cmd : st.cmd;
 #pragma unroll
   for (int i = 0; i < 3; i++) cmd[i] = cmdp[i * B + b];
-  double foot[12], jac[36];
-  if (c->kin_mode == 1) {
-    for (int leg = 0; leg < 4; leg++) leg_fk(c, leg, &q[3 * leg], &foot[3 * leg], &jac[9 * leg]);
-  } else {
+  double foot[3], jac[9];
+  if (c->kin_mode == 1) leg_fk(c, leg, q3, foot, jac);
+  else {
 #pragma unroll
-    for (int i = 0; i < 12; i++) foot[i] = in.foot_pos[i * B + b];
+    for (int i = 0; i < 3; i++) foot[i] = in.foot_pos[(3 * leg + i) * B + b];
 #pragma unroll
-    for (int i = 0; i < 36; i++) jac[i] = in.jac[i * B + b];
+    for (int i = 0; i < 9; i++) jac[i] = in.jac[(9 * leg + i) * B + b];
   }
-  int flags = st.flags[b];
+  const int flags = st.flags[b];
   if (flags & 1) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) st.latched[i * B + b] = foot[i];
+    for (int i = 0; i < 3; i++) st.latched[(3 * leg + i) * B + b] = foot[i];
   }
-  // ---- LocomotionController.update(): gait ----
-  double t = t_now - st.reset_time[b];
-  int desired[4], lstate[4];
-  double phase[4];
-#pragma unroll
-  for (int leg = 0; leg < 4; leg++) gait_leg(c, leg, t, contact[leg], desired[leg], lstate[leg], phase[leg]);
-  // ---- velocity estimator: moving window (Neumaier), divide by window size always ----
-  int rlen = st.ring_len[b], rhead = st.ring_head[b];
+  // ---- gait (own leg) ----
+  const double t = t_now - st.reset_time[b];
+  int desired, lstate;
+  double phase;
+  gait_leg(c, leg, t, contact, desired, lstate, phase);
+  // ---- velocity estimator (all four lanes compute it, leg 0 stores it) ----
+  const int rlen = st.ring_len[b], rhead = st.ring_head[b];
   double vf[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    double s = st.fsum[a * B + b], cr = st.fcorr[a * B + b];
-    size_t slot = ((size_t)a * W + rhead) * B + b;
-    if (rlen >= W) neumaier_add(s, cr, -(double)st.ring[slot]);
-    neumaier_add(s, cr, vw[a]);
-    st.ring[slot] = (float)vw[a];
-    st.fsum[a * B + b] = s; st.fcorr[a * B + b] = cr;
-    vf[a] = (s + cr) / (double)W;
+    double sm = st.fsum[a * B + b], cr = st.fcorr[a * B + b];
+    const size_t slot = ((size_t)a * W + rhead) * B + b;
+    if (rlen >= W) neumaier_add(sm, cr, -(double)st.ring[slot]);
+    neumaier_add(sm, cr, vw[a]);
+    vf[a] = (sm + cr) / (double)W;
+    // all reads of this robot's filter state happen before leg 0 overwrites it
+    __builtin_amdgcn_wave_barrier();
+    if (leg == 0) { st.ring[slot] = (float)vw[a]; st.fsum[a * B + b] = sm; st.fcorr[a * B + b] = cr; }
   }
-  st.ring_head[b] = (rhead + 1) % W;
-  if (rlen < W) st.ring_len[b] = rlen + 1;
   double vb[3];
   {
     double x = -quat[0], y = -quat[1], z = -quat[2], w = quat[3];
@@ -100,30 +103,21 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
     vb[2] = vf[2] + w * tz + (x * ty - y * tx);
   }
   // ---- swing update: latch at desired STANCE->SWING (skipped on the first update after reset) ----
-  int last = st.last_desired[b];
-  if (!(flags & 2)) {
+  const int last = st.last_desired[b];
+  if (!(flags & 2) && desired == RG_LEG_SWING && ((last >> leg) & 1) != RG_LEG_SWING) {
 #pragma unroll
-    for (int leg = 0; leg < 4; leg++)
-      if (desired[leg] == RG_LEG_SWING && ((last >> leg) & 1) != RG_LEG_SWING) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) st.latched[(3 * leg + a) * B + b] = foot[3 * leg + a];
-      }
+    for (int a = 0; a < 3; a++) st.latched[(3 * leg + a) * B + b] = foot[a];
   }
-  int nl = 0;
+  const unsigned long long des_ballot = __ballot(desired == RG_LEG_STANCE);
+  const int desired_bits = (int)((des_ballot >> qbase) & 0xF);   // bit l = leg l desired STANCE (== desired value)
+  // ---- swing get_action (own leg) ----
+  const int valid_old = st.swing_valid[b];
+  double swq[3];
 #pragma unroll
-  for (int leg = 0; leg < 4; leg++) nl |= (desired[leg] & 1) << leg;
-  st.last_desired[b] = nl;
-  st.flags[b] = 0;
-  // ---- swing get_action ----
-  int valid = st.swing_valid[b];
-  double swq[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) swq[i] = st.swing_q[i * B + b];
-  double ftarget[12];
-#pragma unroll
-  for (int i = 0; i < 12; i++) ftarget[i] = 0.0;
-  for (int leg = 0; leg < 4; leg++) {
-    if (lstate[leg] == RG_LEG_STANCE || lstate[leg] == RG_LEG_EARLY_CONTACT) continue;
+  for (int j = 0; j < 3; j++) swq[j] = st.swing_q[(3 * leg + j) * B + b];
+  double ftarget[3] = {0.0, 0.0, 0.0};
+  const bool do_swing = !(lstate == RG_LEG_STANCE || lstate == RG_LEG_EARLY_CONTACT);
+  if (do_swing) {
     const double *hip = &c->hip[3 * leg];
     double tw[3] = {-hip[1], hip[0], 0.0};
     double cv[3] = {vb[0], vb[1], 0.0}, dv[3] = {cmd[0], cmd[1], 0.0};
@@ -136,8 +130,8 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
       target[a] = (hv * c->stance_dur[leg] / 2 - c->swing_kp[a] * (thv - hv)) - dh[a] + (a < 2 ? hip[a] : 0.0);
       start[a] = st.latched[(3 * leg + a) * B + b];
     }
-    double ip = phase[leg], ph;
-    if (ip <= 0.5) ph = 0.8 * sin(ip * M_PI); else ph = 0.8 + (ip - 0.5) * 0.4;
+    double ph;
+    if (phase <= 0.5) ph = 0.8 * sin(phase * M_PI); else ph = 0.8 + (phase - 0.5) * 0.4;
     double fp[3];
     fp[0] = (1 - ph) * start[0] + ph * target[0];
     fp[1] = (1 - ph) * start[1] + ph * target[1];
@@ -147,41 +141,43 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
       double ca = (d1 - d2 * 0.5) / d3, cb = (d2 * 0.25 - d1) / d3;
       fp[2] = ca * ph * ph + cb * ph + start[2];
     }
-    double qo[3];
-    leg_ik(c, leg, fp, &q[3 * leg], qo);
+    leg_ik(c, leg, fp, q3, swq);
 #pragma unroll
-    for (int j = 0; j < 3; j++) { swq[3 * leg + j] = qo[j]; st.swing_q[(3 * leg + j) * B + b] = qo[j]; ftarget[3 * leg + j] = fp[j]; }
-    valid |= 7 << (3 * leg);
+    for (int j = 0; j < 3; j++) { st.swing_q[(3 * leg + j) * B + b] = swq[j]; ftarget[j] = fp[j]; }
   }
-  st.swing_valid[b] = valid;
+  const int swing_bits = (int)((__ballot(do_swing) >> qbase) & 0xF);
+  int valid = valid_old;
+#pragma unroll
+  for (int l = 0; l < 4; l++) if ((swing_bits >> l) & 1) valid |= 7 << (3 * l);
   int emit = 0;
 #pragma unroll
-  for (int j = 0; j < 12; j++) if (((valid >> j) & 1) && desired[j / 3] == RG_LEG_SWING) emit |= 1 << j;
+  for (int j = 0; j < 12; j++) if (((valid >> j) & 1) && !((desired_bits >> (j / 3)) & 1)) emit |= 1 << j;
   // ---- stance record ----
-  int cmask = 0, nc = 0;
-#pragma unroll
-  for (int leg = 0; leg < 4; leg++) if (desired[leg] == RG_LEG_STANCE || desired[leg] == RG_LEG_EARLY_CONTACT) { cmask |= 1 << leg; nc++; }
+  const int cmask = desired_bits;   // contact for the MPC = desired STANCE
+  const int nc = __builtin_popcount(cmask);
   double sr, cr_, sp, cp;
   sincos(rpy[0], &sr, &cr_);
   sincos(rpy[1], &sp, &cp);
-  // feet -> world-aligned frame with Rx(roll) Ry(pitch)   (yaw zeroed)
-  double Rf[9] = {cp, 0, sp, sr * sp, cr_, -sr * cp, -cr_ * sp, sr, cr_ * cp};
-  // body rotation for the inertia: Ry(pitch) Rx(roll)
-  double Rb[9] = {cp, sp * sr, sp * cr_, 0, cr_, -sr, -sp, cp * sr, cp * cr_};
+  // own foot -> world-aligned frame with Rx(roll) Ry(pitch)   (yaw zeroed)
+  double fw[3];
+  fw[0] = cp * foot[0] + sp * foot[2];
+  fw[1] = sr * sp * foot[0] + cr_ * foot[1] - sr * cp * foot[2];
+  fw[2] = -cr_ * sp * foot[0] + sr * foot[1] + cr_ * cp * foot[2];
+  double hz = ((cmask >> leg) & 1) ? fw[2] : 0.0;
+  hz += __shfl_xor(hz, 1);
+  hz += __shfl_xor(hz, 2);
   double *rec = st.rec + (size_t)b * RG_REC_N;
-  rec[REC_ROLL] = rpy[0]; rec[REC_PITCH] = rpy[1];
-  double hz = 0;
 #pragma unroll
-  for (int leg = 0; leg < 4; leg++) {
-    double fw[3];
-    m3vec(Rf, &foot[3 * leg], fw);
-    rec[REC_FEETW + 3 * leg] = fw[0]; rec[REC_FEETW + 3 * leg + 1] = fw[1]; rec[REC_FEETW + 3 * leg + 2] = fw[2];
-    if ((cmask >> leg) & 1) hz += fw[2];
-  }
-  rec[REC_COMZ] = nc > 0 ? fabs(hz / nc) : 0.0;
+  for (int i = 0; i < 3; i++) { rec[REC_FEETW + 3 * leg + i] = fw[i]; rec[REC_SWINGQ + 3 * leg + i] = swq[i]; }
 #pragma unroll
-  for (int i = 0; i < 3; i++) { rec[REC_OMEGA + i] = rate[i]; rec[REC_VBODY + i] = vb[i]; rec[REC_CMD + i] = cmd[i]; }
-  {
+  for (int i = 0; i < 9; i++) rec[REC_JAC + 9 * leg + i] = jac[i];
+  if (leg == 0) {
+    rec[REC_ROLL] = rpy[0]; rec[REC_PITCH] = rpy[1];
+    rec[REC_COMZ] = nc > 0 ? fabs(hz / nc) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { rec[REC_OMEGA + i] = rate[i]; rec[REC_VBODY + i] = vb[i]; rec[REC_CMD + i] = cmd[i]; }
+    // body rotation for the inertia: Ry(pitch) Rx(roll)
+    double Rb[9] = {cp, sp * sr, sp * cr_, 0, cr_, -sr, -sp, cp * sr, cp * cr_};
     double T1[9], Rt[9], Iw[9];
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -191,36 +187,36 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
     m3mul(T1, Rt, Iw);
 #pragma unroll
     for (int i = 0; i < 9; i++) rec[REC_IWINV + i] = Iw[i];
+    rec[REC_INVCP] = 1.0 / cp;
+    rec[REC_TANP] = sp / cp;
+    rec[REC_EMIT] = (double)emit;
+    rec[REC_CONTACT] = (double)cmask;
+    // per-robot persistent scalars
+    st.ring_head[b] = (rhead + 1) % W;
+    if (rlen < W) st.ring_len[b] = rlen + 1;
+    st.last_desired[b] = desired_bits;
+    st.flags[b] = 0;
+    st.swing_valid[b] = valid;
+    const int slot = atomicAdd(&st.counts[nc], 1);
+    st.bins[(size_t)nc * B + slot] = b;
+    if (out.v_body)
+#pragma unroll
+      for (int i = 0; i < 3; i++) out.v_body[b * 3 + i] = (float)vb[i];
   }
-  rec[REC_INVCP] = 1.0 / cp;
-  rec[REC_TANP] = sp / cp;
-#pragma unroll
-  for (int i = 0; i < 36; i++) rec[REC_JAC + i] = jac[i];
-#pragma unroll
-  for (int i = 0; i < 12; i++) rec[REC_SWINGQ + i] = swq[i];
-  rec[REC_EMIT] = (double)emit;
-  rec[REC_CONTACT] = (double)cmask;
-  // ---- bin by number of stance legs ----
-  int slot = atomicAdd(&st.counts[nc], 1);
-  st.bins[(size_t)nc * B + slot] = b;
-  // ---- optional outputs ----
-#pragma unroll
-  for (int leg = 0; leg < 4; leg++) {
-    if (out.leg_state) out.leg_state[b * 4 + leg] = lstate[leg];
-    if (out.desired_state) out.desired_state[b * 4 + leg] = desired[leg];
-    if (out.phase) out.phase[b * 4 + leg] = (float)phase[leg];
-  }
+  // ---- optional outputs (per leg) ----
+  if (out.leg_state) out.leg_state[b * 4 + leg] = lstate;
+  if (out.desired_state) out.desired_state[b * 4 + leg] = desired;
+  if (out.phase) out.phase[b * 4 + leg] = (float)phase;
   if (out.foot_target)
 #pragma unroll
-    for (int i = 0; i < 12; i++) out.foot_target[b * 12 + i] = (float)ftarget[i];
-  if (out.v_body)
-#pragma unroll
-    for (int i = 0; i < 3; i++) out.v_body[b * 3 + i] = (float)vb[i];
+    for (int i = 0; i < 3; i++) out.foot_target[b * 12 + 3 * leg + i] = (float)ftarget[i];
   if (nc == 0) {
     // no stance leg: forces are zero, the action row is complete here
-    for (int j = 0; j < 12; j++) {
+#pragma unroll
+    for (int jj = 0; jj < 3; jj++) {
+      const int j = 3 * leg + jj;
       float *a = out.action + (size_t)b * 60 + 5 * j;
-      if ((emit >> j) & 1) { a[0] = (float)swq[j]; a[1] = (float)c->kp[j]; a[2] = 0.f; a[3] = (float)c->kd[j]; a[4] = 0.f; }
+      if ((emit >> j) & 1) { a[0] = (float)swq[jj]; a[1] = (float)c->kp[j]; a[2] = 0.f; a[3] = (float)c->kd[j]; a[4] = 0.f; }
       else { a[0] = 0.f; a[1] = 0.f; a[2] = 0.f; a[3] = 0.f; a[4] = 0.f; }
       if (out.grf) out.grf[b * 12 + j] = 0.f;
       if (out.tau_stance) out.tau_stance[b * 12 + j] = 0.f;
@@ -765,7 +761,8 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   for (int e = tid; e < H * H; e += NT) { tabN[e] = 2.0 * c->Ntab[e]; tabS[e] = 2.0 * c->Stab[e]; }
   // the one matrix row whose scalar ADMM state this lane owns after the reduce-scatter
   const bool owner = lc < T;
-  const int own_a = TPOW2 ? bitrev_lt<LT>(lc & (T - 1)) : (lc < T ? lc : 0);
+  // T == 8: the reduce-scatter below pairs lanes as (7-i), (i^1), (i^2) -> kept row 4*b2 + 2*b0 + b1
+  const int own_a = (T == 8) ? (4 * ((lc >> 2) & 1) + 2 * (lc & 1) + ((lc >> 1) & 1)) : (TPOW2 ? bitrev_lt<LT>(lc & (T - 1)) : (lc < T ? lc : 0));
   const int io = lr * T + own_a;
   const bool own_real = owner && io < N;
 
@@ -909,7 +906,38 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
       }
       // reduce over the LC lanes of this lane-row
       double tot;
-      if constexpr (TPOW2) {
+      if constexpr (T == 8) {
+        // reduce-scatter over the 8 lanes of a half-row, all in DPP (no LDS round trips):
+        // step 1 pairs i <-> 7-i (row_half_mirror) and splits by bit 2, step 2 pairs i^1 / bit 0,
+        // step 3 pairs i^2 / bit 1.  Lane-rows of 16/32 lanes finish with all-reduce steps.
+        {
+          const bool up = (lc >> 2) & 1;
+#pragma unroll
+          for (int h2 = 0; h2 < 4; h2++) {
+            double keep = up ? acc[4 + h2] : acc[h2];
+            double send = up ? acc[h2] : acc[4 + h2];
+            acc[h2] = keep + dpp_f64<0x141>(send);
+          }
+        }
+        {
+          const bool up = lc & 1;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; h2++) {
+            double keep = up ? acc[2 + h2] : acc[h2];
+            double send = up ? acc[h2] : acc[2 + h2];
+            acc[h2] = keep + dpp_f64<0xB1>(send);
+          }
+        }
+        {
+          const bool up = (lc >> 1) & 1;
+          double keep = up ? acc[1] : acc[0];
+          double send = up ? acc[0] : acc[1];
+          tot = keep + dpp_f64<0x4E>(send);
+        }
+        if constexpr (LG >= 4) tot += dpp_f64<0x128>(tot);
+#pragma unroll
+        for (int k = 4; k < LG; k++) tot += __shfl_xor(tot, 1 << k);
+      } else if constexpr (TPOW2) {
         // reduce-scatter: after step k (xor 2^k) a lane keeps the half selected by bit k of lc
 #pragma unroll
         for (int k = 0; k < LT; k++) {
@@ -1280,7 +1308,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 8, s));
   hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
-  hipLaunchKernelGGL(rg_front_kernel, dim3((B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);
+  hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, s, h->dcfg, h->st, di, dout, t, B);
   HIPCHK(h, hipGetLastError());
   if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
   // Robots with different stance-leg counts are independent; optionally (reserved0 bit3) the four QP

@@ -187,6 +187,17 @@ __device__ __forceinline__ void proj_pyramid(double a, double b, double c, doubl
   z = zz;
 }
 
+// Cross-lane move of a double with a DPP control word (two v_mov_b32_dpp, no LDS):
+// 0xB1 quad_perm[1,0,3,2] (lane^1), 0x4E quad_perm[2,3,0,1] (lane^2), 0x141 row_half_mirror
+// (7-i inside each 8 lanes), 0x128 row_ror:8 (lane^8 inside each 16 lanes).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
 // 1/d from v_rcp_f64 plus two Newton steps (every lane computes it redundantly; the IEEE
 // division sequence is ~4x longer and sat on the critical path of every pivot step).
 __device__ __forceinline__ double fast_rcp(double d) {
