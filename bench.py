@@ -40,6 +40,23 @@ def make_device_state(cfg, B, seed, device):
     return state, cmd, t_off, contact, dev
 
 
+def traffic_from_profile(kernel_name, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r1_traffic.json: FETCH_SIZE and WRITE_SIZE from separate --pmc runs, KiB -> bytes;
+    FETCH_SIZE raw, see tools/summarize_profiles.py).  None when no profile of this batch size is committed."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if int(prof.get("batch", -1)) != int(batch):
+            return None
+        nc = kernel_name.split("nc=")[1][0] if "nc=" in kernel_name else None
+        for k, v in prof["traffic"].items():
+            if (nc and f"tile_kernel<{nc}," in k) or (nc is None and "front" in k):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, budget_s=12.0):
     """Time the oracle (port) on the host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -76,7 +93,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="robots per GPU")
     ap.add_argument("--allgather", action="store_true", help="also all-gather the action slab over RCCL inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--admm-iters", type=int, default=None)
+    ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
     ap.add_argument("--reserved0", type=int, default=0, help="tuning bits passed to rg_mpc_config.reserved0")
     args = ap.parse_args()
 
@@ -98,7 +115,7 @@ def main():
 
     from robot_gym_amd.core.config import MPCConfig
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
-    over = {} if args.admm_iters is None else {"admm_iters": args.admm_iters}
+    over = {} if args.admm_iters is None else {"admm_iters": args.admm_iters, "admm_tol": 0.0}
     over["reserved0"] = args.reserved0
     cfg = MPCConfig.for_robot("ghost", horizon=HORIZON, **over)
     B = args.batch
@@ -130,6 +147,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     nprof, kms, robots = ctl._handle.profile_end(ctl._stream())
+    stats = ctl.solver_stats()
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -138,7 +156,7 @@ def main():
     if rank == 0:
         total_units = world * B * args.steps
         value = total_units / elapsed
-        names = ["rg_front_kernel", "rg_qp_admm_kernel(nc=1)", "rg_qp_admm_kernel(nc=2)", "rg_qp_admm_kernel(nc=3)", "rg_qp_admm_kernel(nc=4)"]
+        names = ["rg_front_kernel", "rg_qp_admm_tile_kernel<nc=1>", "rg_qp_admm_tile_kernel<nc=2>", "rg_qp_admm_tile_kernel<nc=3>", "rg_qp_admm_tile_kernel<nc=4>"]
         units = [B, robots[1], robots[2], robots[3], robots[4]]
         dom = int(np.argmax(kms[:5]))
         dur_s = kms[dom] * 1e-3
@@ -149,10 +167,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batch={B} quadrupeds per GPU, horizon={HORIZON}, randomised (vx,vy,wz) commands (BASELINE configs[2])",
-                       "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} iters={cfg.admm_iters}",
+                       "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}", "admm_iterations": stats,
                        "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None), "sharding": f"{world} x {B} robots, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(names[dom], B),
                          "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,
                          "avg_launch_ms": kms[dom],
                          "kernel_ms": dict(zip(names + ["step_total"], [round(x, 4) for x in kms])),

@@ -90,10 +90,14 @@ typedef struct {
   double ik_damping;        /* lambda^2 */
   double ik_max_step;       /* rad per iteration */
   /* friction-cone ADMM */
-  int32_t admm_iters;       /* fixed iteration count (100) */
-  int32_t reserved0;
+  int32_t admm_iters;       /* iteration cap (300); exactly this many iterations when admm_tol == 0 */
+  int32_t reserved0;        /* tuning/A-B bits, 0 in production */
   double admm_rho;          /* 1e-4 */
   double admm_relax;        /* 1.8 */
+  double admm_tol;          /* stop when no z entry moved more than admm_tol * m * g over the last
+                               admm_check iterations (1e-6); 0 = fixed iteration count */
+  int32_t admm_check;       /* convergence check period (10) */
+  int32_t reserved1;
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per
@@ -152,6 +156,10 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
 /* Introspection for benches/profilers: number of robots per stance-leg count in the last
  * step (HOST out[5]); synchronises the stream. */
 int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream);
+
+/* Solver statistics of the last step (synchronises the stream): sum and max of ADMM iterations over
+ * the robots that had a QP, and the number of such robots. */
+int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots, void *stream);
 
 /* Per-kernel timing with hipEvents recorded on the step's own stream, between the launches of
  * rg_mpc_step.  begin(max_steps) arms it; every following rg_mpc_step records one event after

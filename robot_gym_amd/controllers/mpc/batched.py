@@ -120,6 +120,9 @@ class BatchedMPCController:
         self._handle.hybrid_to_torque(action.data_ptr(), q.data_ptr(), qd.data_ptr(), out.data_ptr(), self._stream())
         return out
 
+    def solver_stats(self):
+        return self._handle.last_solver_stats(self._stream())
+
     def bin_counts(self):
         return self._handle.last_bin_counts(self._stream())
 

@@ -56,10 +56,12 @@ class MPCConfig:
     solver: int = SOLVER_ADMM
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
-    admm_iters: int = 100
+    admm_iters: int = 300        # cap; exactly this many when admm_tol == 0
     reserved0: int = 0  # bit0: force the LDS-resident QP kernel (A/B, generic horizon path)
     admm_rho: float = 1e-4
     admm_relax: float = 1.8
+    admm_tol: float = 1e-6       # stop when no force moved more than admm_tol*m*g over admm_check iterations
+    admm_check: int = 10
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

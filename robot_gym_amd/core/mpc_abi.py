@@ -33,6 +33,7 @@ class CConfig(C.Structure):
         ("motor_off", d * 12), ("jxyz", d * 36), ("jrpy", d * 36), ("jaxis", d * 36), ("toe_xyz", d * 12),
         ("toe_com", d * 12), ("base_com", d * 3), ("ik_iters", i32), ("solver", i32), ("ik_damping", d),
         ("ik_max_step", d), ("admm_iters", i32), ("reserved0", i32), ("admm_rho", d), ("admm_relax", d),
+        ("admm_tol", d), ("admm_check", i32), ("reserved1", i32),
     ]
 
 
@@ -45,7 +46,7 @@ class COutPtrs(C.Structure):
 
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
-           "rg_mpc_last_bin_counts", "rg_mpc_profile_begin", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_profile_begin", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -75,6 +76,8 @@ def load_library(path=None):
     L.rg_mpc_hybrid_to_torque.restype = i32
     L.rg_mpc_last_bin_counts.argtypes = [fp, C.POINTER(i32 * 5), fp]
     L.rg_mpc_last_bin_counts.restype = i32
+    L.rg_mpc_last_solver_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32), fp]
+    L.rg_mpc_last_solver_stats.restype = i32
     L.rg_mpc_profile_begin.argtypes = [fp, i32]
     L.rg_mpc_profile_begin.restype = i32
     L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
@@ -100,7 +103,7 @@ def make_cconfig(cfg):
     c = CConfig()
     c.abi_version = ABI_VERSION
     for name, ctype in CConfig._fields_:
-        if name in ("abi_version",):
+        if name in ("abi_version", "reserved1"):
             continue
         v = getattr(cfg, name)
         if isinstance(v, (tuple, list)) or hasattr(v, "__len__"):
@@ -159,6 +162,12 @@ class MpcHandle:
         out = (i32 * 5)()
         self._check(self._lib.rg_mpc_last_bin_counts(self._h, C.byref(out), stream))
         return list(out)
+
+    def last_solver_stats(self, stream=None):
+        s_, m_, n_ = C.c_int64(), i32(), i32()
+        self._check(self._lib.rg_mpc_last_solver_stats(self._h, C.byref(s_), C.byref(m_), C.byref(n_), stream))
+        return {"iters_sum": s_.value, "iters_max": m_.value, "qp_robots": n_.value,
+                "iters_mean": (s_.value / n_.value) if n_.value else 0.0}
 
     def profile_begin(self, max_steps):
         self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))

@@ -371,7 +371,11 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
     }
     // ---- over-relaxed ADMM:  u = Minv (rho (z - y) - q);  z = Proj_K(relax u + (1-relax) z + y) ----
     double z = (tid < n && (tid % 3) == 2) ? lo : 0.0, y = 0.0;
-    for (int it = 0; it < c->admm_iters; it++) {
+    const double atol = c->admm_abs_tol;
+    const int chk = c->admm_check;
+    double zchk = z;
+    int it = 0, next_chk = chk;
+    for (; it < c->admm_iters; it++) {
       if (tid < n) piv[tid] = rho * (z - y) - qi;
       __syncthreads();
       double u = 0.0;
@@ -390,7 +394,14 @@ rg_qp_admm_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int nc,
         y = wv[tid] - zn;
         z = zn;
       }
+      if (atol > 0.0 && it + 1 == next_chk) {
+        const int moving = tid < n && fabs(z - zchk) > atol;
+        zchk = z;
+        next_chk += chk;
+        if (!__syncthreads_or(moving)) { it++; break; }
+      }
     }
+    if (tid == 0) { atomicAdd(&st.counts[5], it); atomicMax(&st.counts[6], it); }
     // ---- first-step forces (negated), torques, action row ----
     if (tid < m3) grf[3 * nth_leg(cmask, tid / 3) + tid % 3] = -z;
     __syncthreads();
@@ -458,6 +469,8 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
   const double kA = 1.0 / (1.0 + 2.0 * mu * mu), kB = 1.0 / (1.0 + mu * mu);
   for (int e = tid; e < H * H; e += NT) { tabN[e] = 2.0 * c->Ntab[e]; tabS[e] = 2.0 * c->Stab[e]; }
 
+  // Static round-robin over the bin.  (A dynamic atomic work queue was measured 15 % slower here:
+  // under load the CU is throughput-bound, so keeping every slot busy in the tail only adds contention.)
   for (int work = blockIdx.x; work < count; work += gridDim.x) {
     const int b = st.bins[(size_t)NC * B + work];
     __syncthreads();
@@ -593,7 +606,11 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
     // ---- over-relaxed ADMM ----
     double z = (active && (r % 3) == 2) ? lo : 0.0, y = 0.0;
     const int blk = active ? r - r % 3 : 0, dax = r % 3;
-    for (int it = 0; it < c->admm_iters; it++) {
+    const double atol = c->admm_abs_tol;
+    const int chk = c->admm_check;
+    double zchk = z;
+    int it = 0, next_chk = chk;
+    for (; it < c->admm_iters; it++) {
       const double rhs = rho * (z - y) - qi;
       if (active && s == 0) vv[r] = rhs;
       __syncthreads();
@@ -630,7 +647,14 @@ rg_qp_admm_reg_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int
         y = w - zn;
         z = zn;
       }
+      if (atol > 0.0 && it + 1 == next_chk) {
+        const int moving = active && fabs(z - zchk) > atol;
+        zchk = z;
+        next_chk += chk;
+        if (!__syncthreads_or(moving)) { it++; break; }
+      }
     }
+    if (tid == 0) { atomicAdd(&st.counts[5], it); atomicMax(&st.counts[6], it); }
     if (active && s == 0 && r < m3) grf[3 * nth_leg(cmask, r / 3) + r % 3] = -z;
     __syncthreads();
     if (tid < 12) {
@@ -766,6 +790,8 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   const int io = lr * T + own_a;
   const bool own_real = owner && io < N;
 
+  // Static round-robin over the bin.  (A dynamic atomic work queue was measured 15 % slower here:
+  // under load the CU is throughput-bound, so keeping every slot busy in the tail only adds contention.)
   for (int work = blockIdx.x; work < count; work += gridDim.x) {
     const int b = st.bins[(size_t)NC * B + work];
     __syncthreads();
@@ -846,23 +872,28 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
       }
     }
     // ---- symmetric sweep: tile <- entries of -(P + rho I)^-1, pivot-row diagonals offset by +2 ----
+    // Look-ahead: inside step kp the tile row that holds pivot row kp+1 is updated FIRST and published
+    // immediately, so its LDS write -> read latency hides behind the other T-1 row updates.
+    auto publish = [&](int tr, int kb, double *pb) {   // lanes of lane-row kb publish tile row tr (tr static after unrolling)
+      if (lr == kb) {
+        const bool diag = (lc == kb);
+#pragma unroll
+        for (int tb = 0; tb < T; tb += 2) {
+          double v0 = tile[tr][tb], v1 = tile[tr][tb + 1];
+          if (tb == tr) v0 = diag ? v0 - 1.0 : v0;
+          if (tb + 1 == tr) v1 = diag ? v1 - 1.0 : v1;
+          *reinterpret_cast<double2 *>(&pb[lc * T + tb]) = make_double2(v0, v1);
+        }
+        if (diag) pb[NP] = tile[tr][tr];
+      }
+    };
+    publish(0, 0, pbuf);
+    __syncthreads();
     for (int kb = 0; kb < LC; kb++) {
 #pragma unroll
       for (int tr = 0; tr < T; tr++) {
         const int kp = kb * T + tr;
         double *pb = pbuf + (kp & 1) * NPB;
-        if (lr == kb) {
-          const bool diag = (lc == kb);
-#pragma unroll
-          for (int tb = 0; tb < T; tb += 2) {
-            double v0 = tile[tr][tb], v1 = tile[tr][tb + 1];
-            if (tb == tr) v0 = diag ? v0 - 1.0 : v0;
-            if (tb + 1 == tr) v1 = diag ? v1 - 1.0 : v1;
-            *reinterpret_cast<double2 *>(&pb[lc * T + tb]) = make_double2(v0, v1);
-          }
-          if (diag) pb[NP] = tile[tr][tr];
-        }
-        __syncthreads();
         const double invd = fast_rcp(pb[NP]);
         double prow[T], pcol[T];
 #pragma unroll
@@ -871,8 +902,19 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
           double2 b2 = *reinterpret_cast<const double2 *>(&pb[lc * T + t2]);
           prow[t2] = a2.x; prow[t2 + 1] = a2.y; pcol[t2] = b2.x; pcol[t2 + 1] = b2.y;
         }
+        constexpr int dummy = 0; (void)dummy;
+        const int tn = (tr + 1) % T;               // tile row of the next pivot (static)
+        const int kbn = (tr + 1 < T) ? kb : kb + 1; // its lane-row
+        {
+          double ncc = -prow[tn] * invd;
+          if (tn == tr) ncc = (lr == kb) ? invd - 1.0 : ncc;   // only when T == 1
+#pragma unroll
+          for (int tb = 0; tb < T; tb++) tile[tn][tb] = fma(ncc, pcol[tb], tile[tn][tb]);
+        }
+        if (kp + 1 < NP) publish(tn, kbn, pbuf + ((kp + 1) & 1) * NPB);
 #pragma unroll
         for (int ta = 0; ta < T; ta++) {
+          if (ta == tn) continue;
           double ncc = -prow[ta] * invd;
           if (ta == tr) ncc = (lr == kb) ? invd - 1.0 : ncc;
 #pragma unroll
@@ -880,6 +922,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         }
 #pragma unroll
         for (int ta = 0; ta < T; ta++) pin_row<T>(tile[ta]);
+        __syncthreads();
       }
     }
     // ---- over-relaxed ADMM; scalar state lives on the owner lane of each row ----
@@ -887,7 +930,11 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
     const int blk = own_real ? io - io % 3 : 0, dax = io % 3;
     if (owner) vv[io] = own_real ? rho * (z - y) - qi : 0.0;
     __syncthreads();
-    for (int it = 0; it < c->admm_iters; it++) {
+    const double atol = c->admm_abs_tol;
+    const int chk = c->admm_check;
+    double zchk = z;
+    int it = 0, next_chk = chk;
+    for (; it < c->admm_iters; it++) {
       double acc[T];
       {
         double vloc[T];
@@ -975,8 +1022,15 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         z = zn;
         vv[io] = rho * (z - y) - qi;
       }
-      __syncthreads();
+      if (atol > 0.0 && it + 1 == next_chk) {
+        // one robot per workgroup: a data-dependent exit costs no divergence, only this vote
+        const int moving = own_real && fabs(z - zchk) > atol;
+        zchk = z;
+        next_chk += chk;
+        if (!__syncthreads_or(moving)) { it++; break; }
+      } else __syncthreads();
     }
+    if (tid == 0) { atomicAdd(&st.counts[5], it); atomicMax(&st.counts[6], it); }
     if (own_real && io < m3) grf[3 * nth_leg(cmask, io / 3) + io % 3] = -z;
     __syncthreads();
     if (tid < 12) {
@@ -1115,7 +1169,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (c->solver != RG_SOLVER_ADMM) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
-  if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
+  if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 12; i++) if (!(c->motor_dir[i] == 1.0 || c->motor_dir[i] == -1.0)) { err = "motor_dir must be +-1"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 4; i++) {
     if (!(c->duty_factor[i] > 0 && c->duty_factor[i] <= 1) || !(c->stance_duration[i] > 0)) { err = "bad gait timing"; return RG_MPC_ERR_INVALID; }
@@ -1154,6 +1208,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
   d->rho = c->admm_rho; d->relax = c->admm_relax;
+  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
     for (int b = 0; b < H; b++) {
@@ -1396,6 +1451,18 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
   int total = h->B * 12;
   hipLaunchKernelGGL(rg_hybrid_to_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, action, q, qd, tau, h->B);
   HIPCHK(h, hipGetLastError());
+  return RG_MPC_OK;
+}
+
+int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots, void *stream) {
+  if (!h) return RG_MPC_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  int cnt[8];
+  HIPCHK(h, hipMemcpy(cnt, h->st.counts, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (iters_sum) *iters_sum = cnt[5];
+  if (iters_max) *iters_max = cnt[6];
+  if (qp_robots) *qp_robots = cnt[1] + cnt[2] + cnt[3] + cnt[4];
   return RG_MPC_OK;
 }
 

@@ -43,6 +43,8 @@ struct DevCfg {
   double base_com[3];
   double ik_damping, ik_max_step;
   double rho, relax;
+  double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count)
+  int admm_check, pad1;
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };
@@ -60,7 +62,7 @@ struct DevState {
   float *cmd;           // [3][B] rg_mpc_set_command copy
   double *rec;          // [B][RG_REC_N]
   int *bins;            // [5][B]
-  int *counts;          // [8]
+  int *counts;          // [8]: [0..4] robots per stance count, [5] sum of ADMM iterations, [6] max, [7] spare
 };
 
 struct DevIn {

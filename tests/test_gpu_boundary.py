@@ -219,3 +219,19 @@ def test_full_size_properties_batch_4096():
     assert (np.abs(f[..., 0][stance]) <= 0.45 * fz * (1 + 1e-5) + 1e-4).all()
     assert (np.abs(f[..., 1][stance]) <= 0.45 * fz * (1 + 1e-5) + 1e-4).all()
     assert np.isfinite(a1).all()
+
+
+def test_parity_at_baseline_batch_4096(oracle_lib):
+    """Full BASELINE batch against the oracle for two ticks (the oracle needs a few seconds on the GPU
+    box's host cores): catches tails of the fixed-iteration ADMM that small batches miss."""
+    cfg = MPCConfig.for_robot("ghost")
+    state, cmd, t_off = synthetic.make_states(4096, cfg, seed=0)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=2, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=2, jitter=0.1)
+    worst = 0.0
+    for g, o in zip(gpu, orc):
+        m = helpers.compare_tick(g, o)
+        assert m["leg_state_mismatch"] == 0 and m["desired_mismatch"] == 0 and m["phase_bits"] == 0, m
+        assert m["tau_rel_max"] <= 1e-4 and m["grf_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, m
+        worst = max(worst, m["tau_rel_max"])
+    print("worst relative torque error over 8192 robot-ticks:", worst)

@@ -15,8 +15,9 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("rg_front_kernel", "rg_qp_admm_reg_kernel<1", "rg_qp_admm_reg_kernel<2", "rg_qp_admm_reg_kernel<3", "rg_qp_admm_reg_kernel<4",
-              "rg_qp_admm_kernel", "rg_qp_as_kernel", "rg_reset_kernel", "rg_hybrid"):
+    for k in ("rg_front_kernel", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2", "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4",
+              "rg_qp_admm_reg_kernel<1", "rg_qp_admm_reg_kernel<2", "rg_qp_admm_reg_kernel<3", "rg_qp_admm_reg_kernel<4",
+              "rg_qp_admm_kernel", "rg_reset_kernel", "rg_hybrid"):
         if k in name:
             return name[name.index(k):].split("(")[0]
     return None
@@ -51,7 +52,7 @@ with open(os.path.join(dst, f"{tag}_pmc_per_launch.csv"), "w") as f:
         f.write(k.replace(",", ";") + "," + ",".join("%.6g" % c.get(n, float("nan")) for n in names) + "\n")
 bl = os.path.join(src, "bench_line.json")
 meta = json.loads(open(bl).read()) if os.path.exists(bl) and os.path.getsize(bl) else {}
-json.dump({"tag": tag, "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (under rocprofv3)", "traffic": traffic,
+json.dump({"tag": tag, "batch": (meta.get("config", {}).get("workload", "batch=4096").split("batch=")[1].split(" ")[0]), "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (under rocprofv3)", "traffic": traffic,
            "bench_line_under_profiler": meta}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_per_launch.csv")).read())
 print(json.dumps(traffic, indent=1))
