@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--allgather", action="store_true", help="also all-gather the action slab over RCCL inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
+    ap.add_argument("--rho", type=float, default=None)
+    ap.add_argument("--relax", type=float, default=None)
+    ap.add_argument("--tol", type=float, default=None)
     ap.add_argument("--reserved0", type=int, default=0, help="tuning bits passed to rg_mpc_config.reserved0")
     args = ap.parse_args()
 
@@ -117,6 +120,12 @@ def main():
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
     over = {} if args.admm_iters is None else {"admm_iters": args.admm_iters, "admm_tol": 0.0}
     over["reserved0"] = args.reserved0
+    if args.rho is not None:
+        over["admm_rho"] = args.rho
+    if args.relax is not None:
+        over["admm_relax"] = args.relax
+    if args.tol is not None:
+        over["admm_tol"] = args.tol
     cfg = MPCConfig.for_robot("ghost", horizon=HORIZON, **over)
     B = args.batch
     # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard

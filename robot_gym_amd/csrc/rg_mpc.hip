@@ -766,10 +766,15 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   const int tid = threadIdx.x;
   const int lr = tid >> LG, lc = tid & (LC - 1);
   const int count = st.counts[NC];
-  constexpr int NPB = NP + 2;
-  double *pbuf = smem;               // 2 * NPB  ping-pong pivot row; [NP] = 1/d
-  double *vv = pbuf + 2 * NPB;       // NP rhs vector
-  double *wv = vv + NP;              // NP projection input
+  // LDS vectors read as T-wide groups (one group per lane-column) use a padded group stride TS so the
+  // 16-B reads of different groups never share a bank (T = 8: 64-B groups are 2-way conflicting,
+  // rocprof SQ_LDS_BANK_CONFLICT = 30-55 % of LDS cycles; stride 80 B is conflict-free for 8 and 16 groups).
+  constexpr int TS = (T == 8) ? 10 : T;
+  constexpr int NPAD = TS * LC;
+  constexpr int NPB = NPAD + 2;
+  double *pbuf = smem;               // 2 * NPB  ping-pong pivot row (padded); [NPAD] = pivot d
+  double *vv = pbuf + 2 * NPB;       // NPAD rhs vector (padded)
+  double *wv = vv + NPAD;            // NP projection input (unpadded, scalar accesses)
   double *GU = wv + NP;              // m3*m3
   double *GV = GU + m3 * m3;
   double *c1 = GV + m3 * m3;         // N
@@ -789,6 +794,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   const int own_a = (T == 8) ? (4 * ((lc >> 2) & 1) + 2 * (lc & 1) + ((lc >> 1) & 1)) : (TPOW2 ? bitrev_lt<LT>(lc & (T - 1)) : (lc < T ? lc : 0));
   const int io = lr * T + own_a;
   const bool own_real = owner && io < N;
+  const int iov_pad = lr * TS + own_a;   // position of row io in the padded vectors
 
   // Static round-robin over the bin.  (A dynamic atomic work queue was measured 15 % slower here:
   // under load the CU is throughput-bound, so keeping every slot busy in the tail only adds contention.)
@@ -882,9 +888,9 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
           double v0 = tile[tr][tb], v1 = tile[tr][tb + 1];
           if (tb == tr) v0 = diag ? v0 - 1.0 : v0;
           if (tb + 1 == tr) v1 = diag ? v1 - 1.0 : v1;
-          *reinterpret_cast<double2 *>(&pb[lc * T + tb]) = make_double2(v0, v1);
+          *reinterpret_cast<double2 *>(&pb[lc * TS + tb]) = make_double2(v0, v1);
         }
-        if (diag) pb[NP] = tile[tr][tr];
+        if (diag) pb[NPAD] = tile[tr][tr];
       }
     };
     publish(0, 0, pbuf);
@@ -894,12 +900,12 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
       for (int tr = 0; tr < T; tr++) {
         const int kp = kb * T + tr;
         double *pb = pbuf + (kp & 1) * NPB;
-        const double invd = fast_rcp(pb[NP]);
+        const double invd = fast_rcp(pb[NPAD]);
         double prow[T], pcol[T];
 #pragma unroll
         for (int t2 = 0; t2 < T; t2 += 2) {
-          double2 a2 = *reinterpret_cast<const double2 *>(&pb[lr * T + t2]);
-          double2 b2 = *reinterpret_cast<const double2 *>(&pb[lc * T + t2]);
+          double2 a2 = *reinterpret_cast<const double2 *>(&pb[lr * TS + t2]);
+          double2 b2 = *reinterpret_cast<const double2 *>(&pb[lc * TS + t2]);
           prow[t2] = a2.x; prow[t2 + 1] = a2.y; pcol[t2] = b2.x; pcol[t2 + 1] = b2.y;
         }
         constexpr int dummy = 0; (void)dummy;
@@ -928,7 +934,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
     // ---- over-relaxed ADMM; scalar state lives on the owner lane of each row ----
     double z = (own_real && (io % 3) == 2) ? lo : 0.0, y = 0.0;
     const int blk = own_real ? io - io % 3 : 0, dax = io % 3;
-    if (owner) vv[io] = own_real ? rho * (z - y) - qi : 0.0;
+    if (owner) vv[iov_pad] = own_real ? rho * (z - y) - qi : 0.0;
     __syncthreads();
     const double atol = c->admm_abs_tol;
     const int chk = c->admm_check;
@@ -940,7 +946,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         double vloc[T];
 #pragma unroll
         for (int t2 = 0; t2 < T; t2 += 2) {
-          double2 v2 = *reinterpret_cast<const double2 *>(&vv[lc * T + t2]);
+          double2 v2 = *reinterpret_cast<const double2 *>(&vv[lc * TS + t2]);
           vloc[t2] = v2.x; vloc[t2 + 1] = v2.y;
         }
 #pragma unroll
@@ -1020,7 +1026,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         const double zn = (dax == 0) ? px : (dax == 1 ? py : pz);
         y = w - zn;
         z = zn;
-        vv[io] = rho * (z - y) - qi;
+        vv[iov_pad] = rho * (z - y) - qi;
       }
       if (atol > 0.0 && it + 1 == next_chk) {
         // one robot per workgroup: a data-dependent exit costs no divergence, only this vote
@@ -1056,7 +1062,8 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
 template <int NC, int H, int T, int LG, int MINW>
 static hipError_t launch_qp_tile(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
   constexpr int m3 = 3 * NC, N = m3 * H, LC = 1 << LG, NP = T * LC, NT = LC * LC;
-  const size_t lds = sizeof(double) * (size_t)(2 * (NP + 2) + 2 * NP + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
+  constexpr int TS = (T == 8) ? 10 : T, NPAD = TS * LC;
+  const size_t lds = sizeof(double) * (size_t)(2 * (NPAD + 2) + NPAD + NP + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
   int grid = cu_count * 8;
   if (grid > B) grid = B;
   rg_qp_admm_tile_kernel<NC, H, T, LG, MINW><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
