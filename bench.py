@@ -107,7 +107,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:   # launched by torch.distributed.run (any N, also N = 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -162,6 +162,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # PCIe-inclusive rate (reported separately, never `value`): the same steps when the gym side holds the
+    # robot state on the host -- pinned buffers, one upload of all inputs and one download of the action slab per tick.
+    pcie_value = None
+    if world == 1:
+        names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
+        host = {n: dev[n].cpu().pin_memory() for n in names_io}
+        act_host = torch.empty(B, 60, dtype=torch.float32).pin_memory()
+        nio = max(5, min(args.steps, 20))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(nio):
+            for n in names_io:
+                dev[n].copy_(host[n], non_blocking=True)
+            act_host.copy_(ctl.get_action(0.01 * (args.warmup + args.steps + k), dev), non_blocking=True)
+        torch.cuda.synchronize()
+        pcie_value = B * nio / (time.perf_counter() - t1)
+
     if rank == 0:
         total_units = world * B * args.steps
         value = total_units / elapsed
@@ -177,7 +194,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batch={B} quadrupeds per GPU, horizon={HORIZON}, randomised (vx,vy,wz) commands (BASELINE configs[2])",
                        "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}", "admm_iterations": stats,
-                       "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None), "sharding": f"{world} x {B} robots, no data-path collective"},
+                       "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
+                       "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(names[dom], B),
                          "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,

@@ -75,3 +75,24 @@ def test_three_leg_stance_gait(oracle_lib):
     _check(gpu, orc)
     bins = np.array([g["bins"] for g in gpu])
     assert bins[:, 3].sum() > 0
+
+
+def test_flying_gait_zero_to_two_stance_legs_and_odd_batch(oracle_lib):
+    """duty 0.4 trot: every cycle has flight phases (no stance leg -> the front kernel writes the whole
+    action row) and single-pair phases; batch 37 is not a multiple of the wave or quad-group size."""
+    cfg = MPCConfig.for_robot("ghost", duty_factor=(0.4,) * 4, stance_duration=(0.2,) * 4,
+                              init_phase=(0.0, 0.5, 0.5, 0.0), init_state=(1, 1, 1, 1), window=7)
+    state, cmd, t_off = synthetic.make_states(37, cfg, seed=9)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=30, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=30, jitter=0.1)
+    _check(gpu, orc)
+    bins = np.array([g["bins"] for g in gpu])
+    assert bins[:, 0].sum() > 0 and bins[:, 2].sum() > 0 and bins[:, 4].sum() == 0
+
+
+def test_batch_of_one_k3lso_device_kinematics(oracle_lib):
+    cfg = MPCConfig.for_robot("k3lso", kin_mode=1)
+    state, cmd, t_off = synthetic.make_states(1, cfg, seed=10)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=60, jitter=0.2)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=60, jitter=0.2)
+    _check(gpu, orc)
