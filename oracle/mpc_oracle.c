@@ -114,6 +114,12 @@ void orc_gait(const orc_config *c, double t, const int contact[4], int desired[4
   }
 }
 
+/* desired (open-loop) leg states only, for the contact look-ahead extension */
+void orc_gait_desired(const orc_config *c, double t, int desired[4]) {
+  int contact[4] = {1, 1, 1, 1}, ls[4]; double ph[4];
+  orc_gait(c, t, contact, desired, ls, ph);
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* moving-window filter with Neumaier compensation                                       */
 /* [UPSTREAM-RECALL com_velocity_estimator.MovingWindowFilter]: divides by the window    */
@@ -268,9 +274,10 @@ static void expm_dense(int n, const double *M, double *E) {
   free(A); free(T); free(T2);
 }
 
-int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
-                  const double foot_pos[12], const int contact[4], const double cmd[3],
-                  double *Pr, double *qr, int legs[4], double *Ad_out, double *Bd_out) {
+/* dense, all four legs: P (12H x 12H) and q (12H); caller frees */
+static void mpc_build_dense(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+                            const double foot_pos[12], const int contact[4], const double cmd[3],
+                            double **P_out, double **q_out, double *Ad_out, double *Bd_out) {
   const int H = c->horizon, NX = ORC_NX, NU = 12;
   /* yaw-aligned frame: yaw zeroed  [UPSTREAM-RECALL torque_stance_leg_controller.get_action] */
   double rpy[3] = {rpy_in[0], rpy_in[1], 0.0};
@@ -368,6 +375,16 @@ int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omeg
   }
   double *qf = malloc(sizeof(double) * NC);
   for (int i = 0; i < NC; i++) { double s = 0; for (int r = 0; r < NR; r++) s += WB[(size_t)r * NC + i] * sd[r]; qf[i] = 2 * s; }
+  free(xd); free(aqp); free(anb); free(bqp); free(WB); free(sd);
+  *P_out = P; *q_out = qf;
+}
+
+int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+                  const double foot_pos[12], const int contact[4], const double cmd[3],
+                  double *Pr, double *qr, int legs[4], double *Ad_out, double *Bd_out) {
+  const int H = c->horizon, NU = 12, NC = NU * H;
+  double *P, *qf;
+  mpc_build_dense(c, rpy_in, omega, v_body, foot_pos, contact, cmd, &P, &qf, Ad_out, Bd_out);
   /* reduce to contact legs (qpOASES path CopyToMatrix/CopyToVec) */
   int nc = 0; for (int i = 0; i < 4; i++) if (contact[i]) legs[nc++] = i;
   const int n = 3 * nc * H;
@@ -379,8 +396,31 @@ int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omeg
       Pr[(size_t)ir * n + jr] = P[(size_t)i_f * NC + jf];
     }
   }
-  free(xd); free(aqp); free(anb); free(bqp); free(WB); free(P); free(sd); free(qf);
+  free(P); free(qf);
   return nc;
+}
+
+/* EXTENSION: per-step contact schedule.  Same dense P, q; a (step, leg) block
+ * exists only where sched says the leg is in contact at that step. */
+int orc_mpc_build_sched(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+                        const double foot_pos[12], const int contact[4], const int *sched, const double cmd[3],
+                        double *Pr, double *qr, int *var_step, int *var_leg) {
+  const int H = c->horizon, NU = 12, NC = NU * H;
+  double *P, *qf;
+  mpc_build_dense(c, rpy_in, omega, v_body, foot_pos, contact, cmd, &P, &qf, NULL, NULL);
+  int nb = 0;
+  for (int k = 0; k < H; k++) for (int l = 0; l < 4; l++) if (sched[k * 4 + l]) { var_step[nb] = k; var_leg[nb] = l; nb++; }
+  const int n = 3 * nb;
+  for (int ba = 0; ba < nb; ba++) for (int da = 0; da < 3; da++) {
+    int ir = 3 * ba + da, i_f = var_step[ba] * NU + var_leg[ba] * 3 + da;
+    qr[ir] = qf[i_f];
+    for (int bb = 0; bb < nb; bb++) for (int db = 0; db < 3; db++) {
+      int jr = 3 * bb + db, jf = var_step[bb] * NU + var_leg[bb] * 3 + db;
+      Pr[(size_t)ir * n + jr] = P[(size_t)i_f * NC + jf];
+    }
+  }
+  free(P); free(qf);
+  return n;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -634,8 +674,33 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
   int contact[4];
   for (int leg = 0; leg < 4; leg++) contact[leg] = (s->desired[leg] == ORC_STANCE || s->desired[leg] == ORC_EARLY_CONTACT);
   int nc_guess = 0; for (int i = 0; i < 4; i++) nc_guess += contact[i];
-  int n = 3 * nc_guess * H;
   double grf[12] = {0};
+  if (c->contact_lookahead) {
+    /* EXTENSION: step k uses the open-loop desired state at t + k dt_plan (k = 0 is the current tick) */
+    int *sched = malloc(sizeof(int) * 4 * H), nb = 0;
+    for (int k = 0; k < H; k++) {
+      int des[4];
+      orc_gait_desired(c, t + k * c->dt_plan, des);
+      for (int l = 0; l < 4; l++) { sched[k * 4 + l] = (des[l] == ORC_STANCE); nb += sched[k * 4 + l]; }
+    }
+    for (int l = 0; l < 4; l++) sched[l] = contact[l];
+    nb = 0; for (int i = 0; i < 4 * H; i++) nb += sched[i];
+    int n = 3 * nb;
+    if (n > 0 && nc_guess > 0) {
+      double *P = malloc(sizeof(double) * n * n), *qv = malloc(sizeof(double) * n), *u = malloc(sizeof(double) * n), *mu_blk = malloc(sizeof(double) * nb);
+      int *vs = malloc(sizeof(int) * nb), *vl = malloc(sizeof(int) * nb);
+      orc_mpc_build_sched(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, sched, in->cmd, P, qv, vs, vl);
+      for (int b2 = 0; b2 < nb; b2++) mu_blk[b2] = c->mu[0];
+      double mg = c->mass * c->gravity;
+      out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
+      int bad = out->qp_iters < 0;
+      if (!bad) for (int b2 = 0; b2 < nb && vs[b2] == 0; b2++) for (int a = 0; a < 3; a++) grf[3 * vl[b2] + a] = -u[3 * b2 + a];
+      free(P); free(qv); free(u); free(mu_blk); free(vs); free(vl);
+      if (bad) { free(sched); return -1; }
+    }
+    free(sched);
+  } else {
+  int n = 3 * nc_guess * H;
   if (n > 0) {
     double *P = malloc(sizeof(double) * n * n), *qv = malloc(sizeof(double) * n), *u = malloc(sizeof(double) * n), *mu_blk = malloc(sizeof(double) * (n / 3));
     int legs[4];
@@ -648,6 +713,7 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
     if (out->qp_iters < 0) { free(P); free(qv); free(u); free(mu_blk); return -1; }
     for (int l = 0; l < nc; l++) for (int a = 0; a < 3; a++) grf[3 * legs[l] + a] = -u[3 * l + a]; /* negated first step */
     free(P); free(qv); free(u); free(mu_blk);
+  }
   }
   memcpy(out->grf, grf, sizeof(grf));
   for (int leg = 0; leg < 4; leg++) orc_force_to_torque(c, leg, &grf[3 * leg], jac[leg], &out->tau[3 * leg]);

@@ -69,6 +69,7 @@ typedef struct {
   double ik_max_step;       /* per-iteration joint step clamp [rad] */
   /* --- input mode --- */
   int kin_mode;             /* 0: foot_pos + jac supplied; 1: computed from q by chain model */
+  int contact_lookahead;    /* EXTENSION (not upstream): contact flags per horizon step from the open-loop gait at t + k*dt_plan */
 } orc_config;
 
 typedef struct {
@@ -131,6 +132,13 @@ void orc_force_to_torque(const orc_config *c, int leg, const double f[3], const 
 int orc_mpc_build(const orc_config *c, const double rpy[3], const double omega[3], const double v_body[3],
                   const double foot_pos[12], const int contact[4], const double cmd[3],
                   double *P, double *qv, int legs[4], double *Ad /*169 or NULL*/, double *Bd /*13*12 or NULL*/);
+/* Same with a per-step contact schedule sched[k*4+leg] (k = 0..H-1); variables ordered (step, leg in
+ * contact at that step, xyz).  contact[] (step 0) is still what the CoM-height estimate uses.
+ * Returns n; var_step/var_leg (size >= 4H) describe each 3-block. */
+int orc_mpc_build_sched(const orc_config *c, const double rpy[3], const double omega[3], const double v_body[3],
+                        const double foot_pos[12], const int contact[4], const int *sched, const double cmd[3],
+                        double *P, double *qv, int *var_step, int *var_leg);
+void orc_gait_desired(const orc_config *c, double t, int desired[4]);
 /* exact dual active-set solve of  min 1/2 u'Pu + q'u  s.t. friction pyramid + fz box per 3-block.
  * Returns iterations (<0 on failure). */
 int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk /* n/3 */, double fz_min, double fz_max,

@@ -28,7 +28,7 @@ class Config(C.Structure):
         ("motor_kp", d * 12), ("motor_kd", d * 12), ("motor_dir", d * 12), ("motor_off", d * 12),
         ("jxyz", ((d * 3) * 3) * 4), ("jrpy", ((d * 3) * 3) * 4), ("jaxis", ((d * 3) * 3) * 4),
         ("toe_xyz", (d * 3) * 4), ("toe_com", (d * 3) * 4), ("base_com", d * 3),
-        ("ik_iters", i32), ("ik_damping", d), ("ik_max_step", d), ("kin_mode", i32),
+        ("ik_iters", i32), ("ik_damping", d), ("ik_max_step", d), ("kin_mode", i32), ("contact_lookahead", i32),
     ]
 
 

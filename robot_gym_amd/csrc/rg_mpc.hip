@@ -43,6 +43,15 @@ __device__ inline void gait_leg(const DevCfg *c, int leg, double t, int contact,
 // target / trajectory / IK, FK, lever arms) runs in parallel; per-robot values are combined with
 // quad ballots/shuffles and written by the leg-0 lane.  (A lane-per-robot version left 4096 robots
 // on 64 waves with a ~290k-cycle serial chain each.)
+// Open-loop desired state of one leg at horizon step k (look-ahead extension): t + k*dt without FMA
+// contraction, like the float64 CPU arithmetic.
+__device__ inline int gait_desired_at(const DevCfg *c, int leg, double t, int k) {
+  const double tk = __dadd_rn(t, __dmul_rn((double)k, c->dt));
+  int desired, ls; double ph;
+  gait_leg(c, leg, tk, 1, desired, ls, ph);
+  return desired;
+}
+
 __global__ void __launch_bounds__(256)
 rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out, double t_now, int B) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,6 +164,11 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
   // ---- stance record ----
   const int cmask = desired_bits;   // contact for the MPC = desired STANCE
   const int nc = __builtin_popcount(cmask);
+  int sched = 0;                    // bit k: this leg in contact at horizon step k
+  if (c->lookahead) {
+    sched = (cmask >> leg) & 1;
+    for (int k = 1; k < c->H; k++) sched |= (gait_desired_at(c, leg, t, k) == RG_LEG_STANCE) << k;
+  }
   double sr, cr_, sp, cp;
   sincos(rpy[0], &sr, &cr_);
   sincos(rpy[1], &sp, &cp);
@@ -171,6 +185,10 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
   for (int i = 0; i < 3; i++) { rec[REC_FEETW + 3 * leg + i] = fw[i]; rec[REC_SWINGQ + 3 * leg + i] = swq[i]; }
 #pragma unroll
   for (int i = 0; i < 9; i++) rec[REC_JAC + 9 * leg + i] = jac[i];
+  rec[REC_SCHED + leg] = (double)sched;
+  // look-ahead: every robot with a stance leg now solves the full four-leg problem (blocks of a leg that
+  // is not in contact at a step are pinned to zero by the projection)
+  const int bin = c->lookahead ? (nc > 0 ? 4 : 0) : nc;
   if (leg == 0) {
     rec[REC_ROLL] = rpy[0]; rec[REC_PITCH] = rpy[1];
     rec[REC_COMZ] = nc > 0 ? fabs(hz / nc) : 0.0;
@@ -190,15 +208,15 @@ rg_front_kernel(const DevCfg *__restrict__ c, DevState st, DevIn in, DevOut out,
     rec[REC_INVCP] = 1.0 / cp;
     rec[REC_TANP] = sp / cp;
     rec[REC_EMIT] = (double)emit;
-    rec[REC_CONTACT] = (double)cmask;
+    rec[REC_CONTACT] = (double)(c->lookahead ? 15 : cmask);
     // per-robot persistent scalars
     st.ring_head[b] = (rhead + 1) % W;
     if (rlen < W) st.ring_len[b] = rlen + 1;
     st.last_desired[b] = desired_bits;
     st.flags[b] = 0;
     st.swing_valid[b] = valid;
-    const int slot = atomicAdd(&st.counts[nc], 1);
-    st.bins[(size_t)nc * B + slot] = b;
+    const int slot = atomicAdd(&st.counts[bin], 1);
+    st.bins[(size_t)bin * B + slot] = b;
     if (out.v_body)
 #pragma unroll
       for (int i = 0; i < 3; i++) out.v_body[b * 3 + i] = (float)vb[i];
@@ -932,7 +950,10 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
       }
     }
     // ---- over-relaxed ADMM; scalar state lives on the owner lane of each row ----
-    double z = (own_real && (io % 3) == 2) ? lo : 0.0, y = 0.0;
+    // look-ahead extension: a (step, leg) block whose leg is not in contact at that step is pinned to 0
+    bool enabled = true;
+    if (c->lookahead && own_real) enabled = (((int)rec[REC_SCHED + (io % m3) / 3]) >> (io / m3)) & 1;
+    double z = (own_real && enabled && (io % 3) == 2) ? lo : 0.0, y = 0.0;
     const int blk = own_real ? io - io % 3 : 0, dax = io % 3;
     if (owner) vv[iov_pad] = own_real ? rho * (z - y) - qi : 0.0;
     __syncthreads();
@@ -1023,7 +1044,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
       if (own_real) {
         double px, py, pz;
         proj_pyramid(wv[blk], wv[blk + 1], wv[blk + 2], mu, lo, hi, kA, kB, px, py, pz);
-        const double zn = (dax == 0) ? px : (dax == 1 ? py : pz);
+        const double zn = enabled ? ((dax == 0) ? px : (dax == 1 ? py : pz)) : 0.0;
         y = w - zn;
         z = zn;
         vv[iov_pad] = rho * (z - y) - qi;
@@ -1176,6 +1197,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (c->solver != RG_SOLVER_ADMM) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
+  if (c->contact_lookahead && ((c->reserved0 & 7) != 0 || (c->horizon != 10 && c->horizon != 20))) { err = "contact_lookahead needs the tiled QP kernel (reserved0 bits 0-2 clear) and horizon 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 12; i++) if (!(c->motor_dir[i] == 1.0 || c->motor_dir[i] == -1.0)) { err = "motor_dir must be +-1"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 4; i++) {
@@ -1215,7 +1237,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
   d->rho = c->admm_rho; d->relax = c->admm_relax;
-  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check;
+  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
     for (int b = 0; b < H; b++) {

@@ -7,7 +7,7 @@
 #include <stdint.h>
 
 #define RG_MAXH 20
-#define RG_REC_N 88  // doubles per robot in the front->QP record
+#define RG_REC_N 96  // doubles per robot in the front->QP record
 
 // record layout (doubles)
 #define REC_ROLL 0
@@ -24,6 +24,7 @@
 #define REC_SWINGQ 71
 #define REC_EMIT 83
 #define REC_CONTACT 84
+#define REC_SCHED 88    // 4 doubles: per leg, bit k = in contact at horizon step k (look-ahead extension)
 
 struct DevCfg {
   int H, window, kin_mode, ik_iters, admm_iters, pad0;
@@ -44,7 +45,7 @@ struct DevCfg {
   double ik_damping, ik_max_step;
   double rho, relax;
   double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count)
-  int admm_check, pad1;
+  int admm_check, lookahead;
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };

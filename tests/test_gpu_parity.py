@@ -96,3 +96,13 @@ def test_batch_of_one_k3lso_device_kinematics(oracle_lib):
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=60, jitter=0.2)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=60, jitter=0.2)
     _check(gpu, orc)
+
+
+@pytest.mark.parametrize("horizon", [10, 20])
+def test_contact_lookahead_extension(oracle_lib, horizon):
+    """Opt-in per-horizon-step contact schedule (BASELINE config 5 flavour; not in upstream)."""
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon, contact_lookahead=1, admm_iters=600)
+    state, cmd, t_off = synthetic.make_states(48, cfg, seed=11)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=8, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=8, jitter=0.1)
+    _check(gpu, orc)

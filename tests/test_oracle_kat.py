@@ -307,3 +307,31 @@ def test_first_update_after_reset_does_not_latch(oracle_lib):
     inp["foot_pos"][0][1] += (0.05, 0.0, 0.01)
     ob.step(0.01, inp)
     np.testing.assert_array_equal(np.array(ob.states[0].latched[1][:]), first)  # no transition seen -> unchanged
+
+
+def test_contact_lookahead_extension(oracle_lib):
+    """Opt-in extension: with a gait that never swings the look-ahead QP is the
+    constant-contact QP; with a trot it differs, keeps swing legs force-free and satisfies the
+    constraints (KKT residuals are checked inside the oracle solve)."""
+    O = oracle_lib
+    stand = dict(duty_factor=(1.0,) * 4, init_phase=(0.0,) * 4, init_state=(1, 1, 1, 1))
+    inp = None
+    outs = []
+    for la in (0, 1):
+        cfg = helpers.oracle_config(O, MPCConfig.for_robot("ghost", contact_lookahead=la, **stand))
+        inp = _static_input(O, cfg)
+        inp["rpy"][0][:2] = (0.05, -0.08)
+        inp["cmd"][0] = (0.3, 0.0, 0.1)
+        outs.append(O.OracleBatch(cfg, 1).step(0.0, inp)["grf"][0])
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=1e-9)
+    res = []
+    for la in (0, 1):
+        cfg = helpers.oracle_config(O, MPCConfig.for_robot("ghost", contact_lookahead=la))
+        inp = _static_input(O, cfg)
+        inp["cmd"][0] = (0.3, 0.0, 0.0)
+        out = O.OracleBatch(cfg, 1).step(0.22, inp)   # legs 1,2 in stance; 0,3 touch down at 0.25, 1,2 lift at 0.30
+        assert list(out["desired"][0]) == [0, 1, 1, 0] and out["kkt"][0].max() < 1e-7
+        g = out["grf"][0].reshape(4, 3)
+        assert np.abs(g[[0, 3]]).max() == 0.0 and (-g[[1, 2], 2] >= 19.0 - 1e-9).all()
+        res.append(g)
+    assert np.abs(res[0] - res[1]).max() > 1.0   # the plan changes when the swap is anticipated
