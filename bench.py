@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--allgather", action="store_true", help="also all-gather the action slab over RCCL inside the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
+    ap.add_argument("--solver", type=int, default=None, help="0 = ADMM, 1 = exact active set")
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
     ap.add_argument("--tol", type=float, default=None)
@@ -120,6 +121,8 @@ def main():
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
     over = {} if args.admm_iters is None else {"admm_iters": args.admm_iters, "admm_tol": 0.0}
     over["reserved0"] = args.reserved0
+    if args.solver is not None:
+        over["solver"] = args.solver
     if args.rho is not None:
         over["admm_rho"] = args.rho
     if args.relax is not None:

@@ -770,7 +770,7 @@ __device__ __forceinline__ int bitrev_lt(int x) {
   return r;
 }
 
-template <int NC, int H, int T, int LG, int MINW>
+template <int NC, int H, int T, int LG, int MINW, bool AS>
 __global__ void __launch_bounds__((1 << LG) * (1 << LG), MINW)
 rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B) {
   constexpr int m3 = 3 * NC;
@@ -803,7 +803,25 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   double *grf = rec + RG_REC_N;      // 24
   double *tabN = grf + 24;           // H*H
   double *tabS = tabN + H * H;       // H*H
-  const double rho = c->rho, relax = c->relax, mu = c->mu, lo = c->fz_min, hi = c->fz_max, dt = c->dt;
+  // active-set solver storage (only carved when the launch reserved it)
+  constexpr int QMAX = N;            // at most N linearly independent active constraints
+  double *as_x = tabS + H * H;       // NP   primal iterate
+  double *as_g = as_x + NP;          // NP   g = G c_p
+  double *as_z = as_g + NP;          // NP   step direction
+  double *as_pg = as_z + NP;         // 2*NPAD published rows of G (padded groups)
+  double *as_lam = as_pg + 2 * NPAD; // QMAX multipliers
+  double *as_sv = as_lam + QMAX;     // QMAX
+  double *as_r = as_sv + QMAX;       // QMAX
+  double *as_v0 = as_r + QMAX;       // QMAX constraint coefficients
+  double *as_v1 = as_v0 + QMAX;      // QMAX
+  double *as_T = as_v1 + QMAX;       // QMAX*(QMAX+1)/2  packed symmetric (C_A G C_A')^-1
+  int *as_i0 = reinterpret_cast<int *>(as_T + QMAX * (QMAX + 1) / 2);  // QMAX
+  int *as_i1 = as_i0 + QMAX;         // QMAX
+  int *as_id = as_i1 + QMAX;         // QMAX constraint ids
+  int *as_am = as_id + QMAX;         // N/3 active-type mask per block (6 bits)
+  double *as_sc = reinterpret_cast<double *>(as_am + ((N / 3 + 1) & ~1));  // 8 scalars
+  constexpr bool use_as = AS;   // separate instantiation: the active-set path must not cost the ADMM path registers
+  const double rho = use_as ? 0.0 : c->rho, relax = c->relax, mu = c->mu, lo = c->fz_min, hi = c->fz_max, dt = c->dt;
   const double kA = 1.0 / (1.0 + 2.0 * mu * mu), kB = 1.0 / (1.0 + mu * mu);
   for (int e = tid; e < H * H; e += NT) { tabN[e] = 2.0 * c->Ntab[e]; tabS[e] = 2.0 * c->Stab[e]; }
   // the one matrix row whose scalar ADMM state this lane owns after the reduce-scatter
@@ -949,18 +967,247 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         __syncthreads();
       }
     }
+    double z = 0.0;
+    int it = 0;
+    if constexpr (use_as) {
+      // ================= exact dual active-set (range-space form) =================
+      // tile holds -G + 2 I on pivot diagonals, G = P^-1.  x = x0 - G C_A' lam with
+      // (C_A G C_A') lam = ..., kept through T = (C_A G C_A')^-1 (packed symmetric, LDS).
+      // Constraint id = 6*block + type:  0: -fx+mu fz>=0  1: fx+mu fz>=0  2: -fy+mu fz>=0
+      //                                  3:  fy+mu fz>=0  4: fz-lo>=0     5: hi-fz>=0
+      constexpr int NB = N / 3;
+      auto tile_matvec = [&](const double *vin_pad) -> double {   // returns (G v)_io on owner lanes
+        double acc[T];
+        double vloc[T];
+#pragma unroll
+        for (int t2 = 0; t2 < T; t2 += 2) {
+          double2 v2 = *reinterpret_cast<const double2 *>(&vin_pad[lc * TS + t2]);
+          vloc[t2] = v2.x; vloc[t2 + 1] = v2.y;
+        }
+#pragma unroll
+        for (int ta = 0; ta < T; ta++) {
+          double a0 = 0.0;
+#pragma unroll
+          for (int tb = 0; tb < T; tb++) a0 = fma(tile[ta][tb], vloc[tb], a0);
+          acc[ta] = (lr == lc) ? a0 - 2.0 * vloc[ta] : a0;
+        }
+        double tot;
+        if constexpr (T == 8) {
+          {
+            const bool up = (lc >> 2) & 1;
+#pragma unroll
+            for (int h2 = 0; h2 < 4; h2++) { double keep = up ? acc[4 + h2] : acc[h2]; double send = up ? acc[h2] : acc[4 + h2]; acc[h2] = keep + dpp_f64<0x141>(send); }
+          }
+          {
+            const bool up = lc & 1;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) { double keep = up ? acc[2 + h2] : acc[h2]; double send = up ? acc[h2] : acc[2 + h2]; acc[h2] = keep + dpp_f64<0xB1>(send); }
+          }
+          { const bool up = (lc >> 1) & 1; double keep = up ? acc[1] : acc[0]; double send = up ? acc[0] : acc[1]; tot = keep + dpp_f64<0x4E>(send); }
+          if constexpr (LG >= 4) tot += dpp_f64<0x128>(tot);
+#pragma unroll
+          for (int kx = 4; kx < LG; kx++) tot += __shfl_xor(tot, 1 << kx);
+        } else {
+#pragma unroll
+          for (int ta = 0; ta < T; ta++) {
+#pragma unroll
+            for (int kx = 0; kx < LG; kx++) acc[ta] += __shfl_xor(acc[ta], 1 << kx);
+          }
+          tot = acc[0];
+#pragma unroll
+          for (int ta = 1; ta < T; ta++) tot = (own_a == ta) ? acc[ta] : tot;
+        }
+        return -tot;
+      };
+      auto Tidx = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
+      // --- x0 = -G q ---
+      double *wpad = vv;   // padded mat-vec input (reuses the ADMM rhs buffer)
+      if (owner) wpad[iov_pad] = own_real ? qi : 0.0;
+      if (tid < NB) as_am[tid] = 0;
+      __syncthreads();
+      double x = -tile_matvec(wpad);
+      if (!own_real) x = 0.0;
+      if (owner) as_x[io] = x;
+      int q = 0;
+      const double vtol = 1e-9 * (1.0 + hi * 1e-3);
+      const int it_cap = 6 * N + 60;
+      __syncthreads();
+      for (; it < it_cap; it++) {
+        // --- S1: most violated inactive constraint (threads < NB, wave 0) ---
+        if (tid < 64) {
+          double best = 0.0; int bid = -1;
+          for (int blk2 = tid; blk2 < NB; blk2 += 64) {
+            const double fx = as_x[3 * blk2], fy = as_x[3 * blk2 + 1], fz = as_x[3 * blk2 + 2];
+            const int am = as_am[blk2];
+            const double sv6[6] = {-fx + mu * fz, fx + mu * fz, -fy + mu * fz, fy + mu * fz, fz - lo, hi - fz};
+#pragma unroll
+            for (int ty = 0; ty < 6; ty++) if (!((am >> ty) & 1) && sv6[ty] < best) { best = sv6[ty]; bid = 6 * blk2 + ty; }
+          }
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const double ob = __shfl_xor(best, o); const int oid = __shfl_xor(bid, o);
+            if (ob < best || (ob == best && oid >= 0 && (bid < 0 || oid < bid))) { best = ob; bid = oid; }
+          }
+          if (tid == 0) { as_sc[0] = best; as_sc[1] = (double)bid; }
+        }
+        __syncthreads();
+        double s_p = as_sc[0];
+        const int pid = (int)as_sc[1];
+        if (pid < 0 || s_p >= -vtol) break;
+        const int pblk = pid / 6, pty = pid % 6;
+        const int pi0 = (pty < 2) ? 3 * pblk : (pty < 4 ? 3 * pblk + 1 : 3 * pblk + 2);
+        const int pi1 = 3 * pblk + 2;
+        const double pv0 = (pty == 0 || pty == 2 || pty == 5) ? -1.0 : 1.0;
+        const double pv1 = (pty < 4) ? mu : 0.0;
+        // --- S2: publish rows pi0 (and pi1) of G; S3: g = G c_p ---
+        {
+          const int r0l = pi0 / T, r0a = pi0 % T, r1l = pi1 / T, r1a = pi1 % T;
+#pragma unroll
+          for (int ta = 0; ta < T; ta++) {
+            if (lr == r0l && ta == r0a) {
+#pragma unroll
+              for (int tb = 0; tb < T; tb++) as_pg[lc * TS + tb] = -(tile[ta][tb] - ((lc == lr && tb == ta) ? 2.0 : 0.0));
+            }
+            if (pv1 != 0.0 && lr == r1l && ta == r1a) {
+#pragma unroll
+              for (int tb = 0; tb < T; tb++) as_pg[NPAD + lc * TS + tb] = -(tile[ta][tb] - ((lc == lr && tb == ta) ? 2.0 : 0.0));
+            }
+          }
+        }
+        __syncthreads();
+        if (owner) {
+          const int ipad = (io / T) * TS + io % T;
+          double gi = pv0 * as_pg[ipad];
+          if (pv1 != 0.0) gi += pv1 * as_pg[NPAD + ipad];
+          as_g[io] = own_real ? gi : 0.0;
+        }
+        __syncthreads();
+        const double sigma = pv0 * as_g[pi0] + pv1 * as_g[pi1];
+        double lam_p = 0.0;
+        // --- inner loop: steps for constraint p until it becomes active (full step) ---
+        bool failed = false;
+        for (int inner = 0; inner < 2 * N + 8; inner++) {
+          // S4: sv = C_A g
+          if (tid < q) as_sv[tid] = as_v0[tid] * as_g[as_i0[tid]] + as_v1[tid] * as_g[as_i1[tid]];
+          __syncthreads();
+          // S5: r = T sv
+          if (tid < q) {
+            double rk = 0.0;
+            for (int j = 0; j < q; j++) rk = fma(as_T[Tidx(tid, j)], as_sv[j], rk);
+            as_r[tid] = rk;
+          }
+          // S6: w = c_p - C_A' r  (dense, padded)
+          if (owner) wpad[iov_pad] = (io == pi0 ? pv0 : 0.0) + (io == pi1 ? pv1 : 0.0);
+          __syncthreads();
+          if (tid < q) {
+            const double rk = as_r[tid];
+            const int a0 = as_i0[tid], a1 = as_i1[tid];
+            atomicAdd(&wpad[(a0 / T) * TS + a0 % T], -rk * as_v0[tid]);
+            if (as_v1[tid] != 0.0) atomicAdd(&wpad[(a1 / T) * TS + a1 % T], -rk * as_v1[tid]);
+          }
+          __syncthreads();
+          // S7: z = G w
+          double zz = tile_matvec(wpad);
+          if (!own_real) zz = 0.0;
+          if (owner) as_z[io] = zz;
+          // S8: step lengths
+          if (tid < 64) {
+            double t1 = INFINITY; int lsel = -1;
+            for (int kq = tid; kq < q; kq += 64) {
+              const double rk = as_r[kq];
+              if (rk > 0.0) { const double cand = as_lam[kq] / rk; if (cand < t1) { t1 = cand; lsel = kq; } }
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const double ot = __shfl_xor(t1, o); const int ol = __shfl_xor(lsel, o);
+              if (ot < t1 || (ot == t1 && ol >= 0 && (lsel < 0 || ol < lsel))) { t1 = ot; lsel = ol; }
+            }
+            if (tid == 0) { as_sc[2] = t1; as_sc[3] = (double)lsel; }
+          }
+          __syncthreads();
+          const double dz = pv0 * as_z[pi0] + pv1 * as_z[pi1];   // c_p' z = sigma - sv' r  (>= 0)
+          const double t1 = as_sc[2];
+          const int lsel = (int)as_sc[3];
+          const bool have_z = dz > 1e-13 * (1.0 + fabs(sigma));
+          const double t2 = have_z ? -s_p / dz : INFINITY;
+          const double tt = fmin(t1, t2);
+          if (!(tt < INFINITY)) { failed = true; break; }
+          // S9: take the step
+          if (have_z) { x = fma(tt, zz, x); if (owner) as_x[io] = x; s_p = fma(tt, dz, s_p); }
+          if (tid < q) as_lam[tid] -= tt * as_r[tid];
+          lam_p += tt;
+          const bool full = have_z && (t2 <= t1);
+          __syncthreads();
+          if (full) {
+            // add p: T <- [[T + r r'/dz, -r/dz], [-r'/dz, 1/dz]]
+            const double idz = 1.0 / dz;
+            for (int e = tid; e < q * (q + 1) / 2; e += NT) {
+              int i2 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+              while (i2 * (i2 + 1) / 2 > e) i2--;
+              while ((i2 + 1) * (i2 + 2) / 2 <= e) i2++;
+              const int j2 = e - i2 * (i2 + 1) / 2;
+              as_T[e] = fma(as_r[i2] * idz, as_r[j2], as_T[e]);
+            }
+            if (tid < q) as_T[q * (q + 1) / 2 + tid] = -as_r[tid] * idz;
+            if (tid == 0) {
+              as_T[q * (q + 1) / 2 + q] = idz;
+              as_i0[q] = pi0; as_i1[q] = pi1; as_v0[q] = pv0; as_v1[q] = pv1; as_id[q] = pid; as_lam[q] = lam_p;
+              as_am[pblk] |= 1 << pty;
+            }
+            q++;
+            __syncthreads();
+            break;
+          }
+          // partial step: drop constraint lsel, keep working on p
+          {
+            const int l = lsel;
+            const double tau_l = as_T[Tidx(l, l)];
+            const double itau = 1.0 / tau_l;
+            // column l of T into as_sv (scratch), then downdate all pairs not touching l
+            if (tid < q) as_sv[tid] = as_T[Tidx(tid, l)];
+            __syncthreads();
+            for (int e = tid; e < q * (q + 1) / 2; e += NT) {
+              int i2 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+              while (i2 * (i2 + 1) / 2 > e) i2--;
+              while ((i2 + 1) * (i2 + 2) / 2 <= e) i2++;
+              const int j2 = e - i2 * (i2 + 1) / 2;
+              if (i2 != l && j2 != l) as_T[e] = fma(-as_sv[i2] * itau, as_sv[j2], as_T[e]);
+            }
+            __syncthreads();
+            // move the last active constraint into slot l
+            const int last = q - 1;
+            if (l != last) {
+              if (tid < last && tid != l) as_T[Tidx(l, tid)] = as_T[Tidx(last, tid)];
+              if (tid == 0) as_T[Tidx(l, l)] = as_T[Tidx(last, last)];
+            }
+            if (tid == 0) {
+              const int did = as_id[l];
+              as_am[did / 6] &= ~(1 << (did % 6));
+              if (l != last) { as_i0[l] = as_i0[last]; as_i1[l] = as_i1[last]; as_v0[l] = as_v0[last]; as_v1[l] = as_v1[last]; as_id[l] = as_id[last]; as_lam[l] = as_lam[last]; }
+            }
+            q--;
+            __syncthreads();
+          }
+        }
+        if (failed) { if (tid == 0) atomicAdd(&st.counts[7], 1); break; }
+      }
+      if (it >= it_cap && tid == 0) atomicAdd(&st.counts[7], 1);
+      z = x;
+    } else {
     // ---- over-relaxed ADMM; scalar state lives on the owner lane of each row ----
     // look-ahead extension: a (step, leg) block whose leg is not in contact at that step is pinned to 0
     bool enabled = true;
     if (c->lookahead && own_real) enabled = (((int)rec[REC_SCHED + (io % m3) / 3]) >> (io / m3)) & 1;
-    double z = (own_real && enabled && (io % 3) == 2) ? lo : 0.0, y = 0.0;
+    z = (own_real && enabled && (io % 3) == 2) ? lo : 0.0;
+    double y = 0.0;
     const int blk = own_real ? io - io % 3 : 0, dax = io % 3;
     if (owner) vv[iov_pad] = own_real ? rho * (z - y) - qi : 0.0;
     __syncthreads();
     const double atol = c->admm_abs_tol;
     const int chk = c->admm_check;
     double zchk = z;
-    int it = 0, next_chk = chk;
+    int next_chk = chk;
+    it = 0;
     for (; it < c->admm_iters; it++) {
       double acc[T];
       {
@@ -1057,6 +1304,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         if (!__syncthreads_or(moving)) { it++; break; }
       } else __syncthreads();
     }
+    }
     if (tid == 0) { atomicAdd(&st.counts[5], it); atomicMax(&st.counts[6], it); }
     if (own_real && io < m3) grf[3 * nth_leg(cmask, io / 3) + io % 3] = -z;
     __syncthreads();
@@ -1080,32 +1328,49 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   }
 }
 
-template <int NC, int H, int T, int LG, int MINW>
-static hipError_t launch_qp_tile(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
+template <int NC, int H, int T, int LG, int MINW, bool AS>
+static hipError_t launch_qp_tile_impl(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
   constexpr int m3 = 3 * NC, N = m3 * H, LC = 1 << LG, NP = T * LC, NT = LC * LC;
   constexpr int TS = (T == 8) ? 10 : T, NPAD = TS * LC;
-  const size_t lds = sizeof(double) * (size_t)(2 * (NPAD + 2) + NPAD + NP + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
+  size_t lds = sizeof(double) * (size_t)(2 * (NPAD + 2) + NPAD + NP + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
+  if (AS) lds += sizeof(double) * (size_t)(3 * NP + 2 * NPAD + 5 * N + N * (N + 1) / 2 + 8) + sizeof(int) * (size_t)(3 * N + ((N / 3 + 1) & ~1));
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static size_t attr_set = 0;
+  if (lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)rg_qp_admm_tile_kernel<NC, H, T, LG, MINW, AS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
   int grid = cu_count * 8;
   if (grid > B) grid = B;
-  rg_qp_admm_tile_kernel<NC, H, T, LG, MINW><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
+  rg_qp_admm_tile_kernel<NC, H, T, LG, MINW, AS><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
   return hipGetLastError();
 }
 
-static bool launch_qp_tile_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err) {
+template <int NC, int H, int T, int LG, int MINW>
+static hipError_t launch_qp_tile(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s, bool active_set) {
+  if (active_set) {
+    if constexpr (H == 10) return launch_qp_tile_impl<NC, H, T, LG, MINW, true>(dcfg, st, dout, B, cu_count, s);
+    else return hipErrorInvalidValue;
+  }
+  return launch_qp_tile_impl<NC, H, T, LG, MINW, false>(dcfg, st, dout, B, cu_count, s);
+}
+
+static bool launch_qp_tile_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err, bool active_set) {
   *err = hipSuccess;
   if (H == 10) {
     switch (nc) {
-      case 1: *err = launch_qp_tile<1, 10, 4, 3, 2>(dcfg, st, dout, B, cu, s); return true;   // 30 -> 32
-      case 2: *err = launch_qp_tile<2, 10, 8, 3, 2>(dcfg, st, dout, B, cu, s); return true;   // 60 -> 64, one wave
-      case 3: *err = launch_qp_tile<3, 10, 6, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 90 -> 96, four waves
-      case 4: *err = launch_qp_tile<4, 10, 8, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 120 -> 128, four waves
+      case 1: *err = launch_qp_tile<1, 10, 4, 3, 2>(dcfg, st, dout, B, cu, s, active_set); return true;   // 30 -> 32
+      case 2: *err = launch_qp_tile<2, 10, 8, 3, 2>(dcfg, st, dout, B, cu, s, active_set); return true;   // 60 -> 64, one wave
+      case 3: *err = launch_qp_tile<3, 10, 6, 4, 2>(dcfg, st, dout, B, cu, s, active_set); return true;   // 90 -> 96, four waves
+      case 4: *err = launch_qp_tile<4, 10, 8, 4, 2>(dcfg, st, dout, B, cu, s, active_set); return true;   // 120 -> 128, four waves
     }
   } else if (H == 20) {
     switch (nc) {
-      case 1: *err = launch_qp_tile<1, 20, 8, 3, 2>(dcfg, st, dout, B, cu, s); return true;   // 60 -> 64
-      case 2: *err = launch_qp_tile<2, 20, 8, 4, 2>(dcfg, st, dout, B, cu, s); return true;   // 120 -> 128
-      case 3: *err = launch_qp_tile<3, 20, 6, 5, 1>(dcfg, st, dout, B, cu, s); return true;   // 180 -> 192, sixteen waves
-      case 4: *err = launch_qp_tile<4, 20, 8, 5, 1>(dcfg, st, dout, B, cu, s); return true;   // 240 -> 256, sixteen waves
+      case 1: *err = launch_qp_tile<1, 20, 8, 3, 2>(dcfg, st, dout, B, cu, s, active_set); return true;   // 60 -> 64
+      case 2: *err = launch_qp_tile<2, 20, 8, 4, 2>(dcfg, st, dout, B, cu, s, active_set); return true;   // 120 -> 128
+      case 3: *err = launch_qp_tile<3, 20, 6, 5, 1>(dcfg, st, dout, B, cu, s, active_set); return true;   // 180 -> 192, sixteen waves
+      case 4: *err = launch_qp_tile<4, 20, 8, 5, 1>(dcfg, st, dout, B, cu, s, active_set); return true;   // 240 -> 256, sixteen waves
     }
   }
   return false;
@@ -1196,7 +1461,8 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
-  if (c->solver != RG_SOLVER_ADMM) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
+  if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
+  if (c->solver == RG_SOLVER_ACTIVE_SET && ((c->reserved0 & 7) != 0 || c->horizon != 10 || c->contact_lookahead)) { err = "the active-set solver needs the tiled QP kernel, horizon 10 and no contact look-ahead"; return RG_MPC_ERR_INVALID; }
   if (c->contact_lookahead && ((c->reserved0 & 7) != 0 || (c->horizon != 10 && c->horizon != 20))) { err = "contact_lookahead needs the tiled QP kernel (reserved0 bits 0-2 clear) and horizon 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 12; i++) if (!(c->motor_dir[i] == 1.0 || c->motor_dir[i] == -1.0)) { err = "motor_dir must be +-1"; return RG_MPC_ERR_INVALID; }
@@ -1237,7 +1503,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
   d->rho = c->admm_rho; d->relax = c->admm_relax;
-  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0;
+  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
     for (int b = 0; b < H; b++) {
@@ -1410,7 +1676,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     bool launched = false;
     if (!h->force_lds_kernel && h->qp_variant != 2 && h->qp_variant != 1) {
       hipError_t lerr;
-      if (launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr)) {
+      if (launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, h->cfg.solver == RG_SOLVER_ACTIVE_SET)) {
         HIPCHK(h, lerr);
         launched = true;
       }

@@ -46,6 +46,7 @@ struct DevCfg {
   double rho, relax;
   double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count)
   int admm_check, lookahead;
+  int solver, pad2;
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };
