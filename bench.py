@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
     ap.add_argument("--solver", type=int, default=None, help="0 = ADMM, 1 = exact active set")
+    ap.add_argument("--cap", type=int, default=None, help="ADMM iteration cap (keeps the convergence test)")
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
     ap.add_argument("--tol", type=float, default=None)
@@ -123,6 +124,8 @@ def main():
     over["reserved0"] = args.reserved0
     if args.solver is not None:
         over["solver"] = args.solver
+    if args.cap is not None:
+        over["admm_iters"] = args.cap
     if args.rho is not None:
         over["admm_rho"] = args.rho
     if args.relax is not None:

@@ -46,7 +46,11 @@ typedef enum {
  * model/robots/ghost/ctrl_constants.py:32-37 */
 enum { RG_LEG_SWING = 0, RG_LEG_STANCE = 1, RG_LEG_EARLY_CONTACT = 2, RG_LEG_LOSE_CONTACT = 3 };
 
-enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1 };
+/* RG_SOLVER_ADMM: friction-cone ADMM only (iteration cap admm_iters).
+ * RG_SOLVER_ACTIVE_SET: exact dual active-set method only.
+ * RG_SOLVER_AUTO: ADMM first; robots that have not converged after admm_iters iterations are
+ *   re-solved exactly by the active-set kernel (second launch over a retry list). */
+enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1, RG_SOLVER_AUTO = 2 };
 
 /* Everything MPCController._setup_controller wires (mpc_controller.py:28-66) plus the
  * upstream module defaults it does not override, as explicit fields. */
@@ -86,11 +90,11 @@ typedef struct {
   double toe_com[12];
   double base_com[3];
   int32_t ik_iters;         /* fixed damped-Newton iteration count (12) */
-  int32_t solver;           /* RG_SOLVER_* */
+  int32_t solver;           /* RG_SOLVER_* (default RG_SOLVER_AUTO) */
   double ik_damping;        /* lambda^2 */
   double ik_max_step;       /* rad per iteration */
   /* friction-cone ADMM */
-  int32_t admm_iters;       /* iteration cap (300); exactly this many iterations when admm_tol == 0 */
+  int32_t admm_iters;       /* ADMM iteration cap (300); exactly this many iterations when admm_tol == 0 */
   int32_t reserved0;        /* tuning/A-B bits, 0 in production */
   double admm_rho;          /* 1e-4 */
   double admm_relax;        /* 1.8 */
@@ -158,9 +162,11 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
  * step (HOST out[5]); synchronises the stream. */
 int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream);
 
-/* Solver statistics of the last step (synchronises the stream): sum and max of ADMM iterations over
- * the robots that had a QP, and the number of such robots. */
-int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots, void *stream);
+/* Solver statistics of the last step (synchronises the stream): sum and max of solver iterations
+ * (ADMM iterations / active-set constraint additions) over the robots that had a QP, the number of
+ * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO) and how many solves failed. */
+int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
+                             int32_t *retried, int32_t *failures, void *stream);
 
 /* Per-kernel timing with hipEvents recorded on the step's own stream, between the launches of
  * rg_mpc_step.  begin(max_steps) arms it; every following rg_mpc_step records one event after

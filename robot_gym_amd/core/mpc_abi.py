@@ -76,7 +76,7 @@ def load_library(path=None):
     L.rg_mpc_hybrid_to_torque.restype = i32
     L.rg_mpc_last_bin_counts.argtypes = [fp, C.POINTER(i32 * 5), fp]
     L.rg_mpc_last_bin_counts.restype = i32
-    L.rg_mpc_last_solver_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32), fp]
+    L.rg_mpc_last_solver_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), fp]
     L.rg_mpc_last_solver_stats.restype = i32
     L.rg_mpc_profile_begin.argtypes = [fp, i32]
     L.rg_mpc_profile_begin.restype = i32
@@ -164,10 +164,10 @@ class MpcHandle:
         return list(out)
 
     def last_solver_stats(self, stream=None):
-        s_, m_, n_ = C.c_int64(), i32(), i32()
-        self._check(self._lib.rg_mpc_last_solver_stats(self._h, C.byref(s_), C.byref(m_), C.byref(n_), stream))
-        return {"iters_sum": s_.value, "iters_max": m_.value, "qp_robots": n_.value,
-                "iters_mean": (s_.value / n_.value) if n_.value else 0.0}
+        s_, m_, n_, r_, f_ = C.c_int64(), i32(), i32(), i32(), i32()
+        self._check(self._lib.rg_mpc_last_solver_stats(self._h, C.byref(s_), C.byref(m_), C.byref(n_), C.byref(r_), C.byref(f_), stream))
+        return {"iters_sum": s_.value, "iters_max": m_.value, "qp_robots": n_.value, "retried_exact": r_.value,
+                "failures": f_.value, "iters_mean": (s_.value / n_.value) if n_.value else 0.0}
 
     def profile_begin(self, max_steps):
         self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))

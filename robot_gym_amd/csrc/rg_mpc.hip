@@ -772,7 +772,7 @@ __device__ __forceinline__ int bitrev_lt(int x) {
 
 template <int NC, int H, int T, int LG, int MINW, bool AS>
 __global__ void __launch_bounds__((1 << LG) * (1 << LG), MINW)
-rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B) {
+rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B, int retry_pass) {
   constexpr int m3 = 3 * NC;
   constexpr int N = m3 * H;          // real QP variables
   constexpr int LC = 1 << LG;        // lanes per side
@@ -783,7 +783,9 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   static_assert(NP >= N && T % 2 == 0 && T <= LC, "tile/grid must cover the problem");
   const int tid = threadIdx.x;
   const int lr = tid >> LG, lc = tid & (LC - 1);
-  const int count = st.counts[NC];
+  // retry_pass: work list = robots the ADMM pass could not converge (RG_SOLVER_AUTO)
+  const int list = retry_pass ? 5 + NC : NC;
+  const int count = st.counts[retry_pass ? 8 + NC : NC];
   // LDS vectors read as T-wide groups (one group per lane-column) use a padded group stride TS so the
   // 16-B reads of different groups never share a bank (T = 8: 64-B groups are 2-way conflicting,
   // rocprof SQ_LDS_BANK_CONFLICT = 30-55 % of LDS cycles; stride 80 B is conflict-free for 8 and 16 groups).
@@ -835,7 +837,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
   // Static round-robin over the bin.  (A dynamic atomic work queue was measured 15 % slower here:
   // under load the CU is throughput-bound, so keeping every slot busy in the tail only adds contention.)
   for (int work = blockIdx.x; work < count; work += gridDim.x) {
-    const int b = st.bins[(size_t)NC * B + work];
+    const int b = st.bins[(size_t)list * B + work];
     __syncthreads();
     for (int e = tid; e < RG_REC_N; e += NT) rec[e] = st.rec[(size_t)b * RG_REC_N + e];
     if (tid < 24) grf[tid] = 0.0;
@@ -1019,81 +1021,29 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         }
         return -tot;
       };
-      auto Tidx = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
-      // --- x0 = -G q ---
+      // --- state machine with ONE mat-vec site: pass 0 computes x0 = -G q, later passes one step each ---
       double *wpad = vv;   // padded mat-vec input (reuses the ADMM rhs buffer)
-      if (owner) wpad[iov_pad] = own_real ? qi : 0.0;
       if (tid < NB) as_am[tid] = 0;
-      __syncthreads();
-      double x = -tile_matvec(wpad);
-      if (!own_real) x = 0.0;
-      if (owner) as_x[io] = x;
-      int q = 0;
+      double x = 0.0, s_p = 0.0, lam_p = 0.0, sigma = 0.0;
+      int q = 0, pid = -1, pi0 = 0, pi1 = 0, pblk = 0, pty = 0;
+      double pv0 = 0.0, pv1 = 0.0;
       const double vtol = 1e-9 * (1.0 + hi * 1e-3);
-      const int it_cap = 6 * N + 60;
-      __syncthreads();
-      for (; it < it_cap; it++) {
-        // --- S1: most violated inactive constraint (threads < NB, wave 0) ---
-        if (tid < 64) {
-          double best = 0.0; int bid = -1;
-          for (int blk2 = tid; blk2 < NB; blk2 += 64) {
-            const double fx = as_x[3 * blk2], fy = as_x[3 * blk2 + 1], fz = as_x[3 * blk2 + 2];
-            const int am = as_am[blk2];
-            const double sv6[6] = {-fx + mu * fz, fx + mu * fz, -fy + mu * fz, fy + mu * fz, fz - lo, hi - fz};
-#pragma unroll
-            for (int ty = 0; ty < 6; ty++) if (!((am >> ty) & 1) && sv6[ty] < best) { best = sv6[ty]; bid = 6 * blk2 + ty; }
-          }
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const double ob = __shfl_xor(best, o); const int oid = __shfl_xor(bid, o);
-            if (ob < best || (ob == best && oid >= 0 && (bid < 0 || oid < bid))) { best = ob; bid = oid; }
-          }
-          if (tid == 0) { as_sc[0] = best; as_sc[1] = (double)bid; }
-        }
-        __syncthreads();
-        double s_p = as_sc[0];
-        const int pid = (int)as_sc[1];
-        if (pid < 0 || s_p >= -vtol) break;
-        const int pblk = pid / 6, pty = pid % 6;
-        const int pi0 = (pty < 2) ? 3 * pblk : (pty < 4 ? 3 * pblk + 1 : 3 * pblk + 2);
-        const int pi1 = 3 * pblk + 2;
-        const double pv0 = (pty == 0 || pty == 2 || pty == 5) ? -1.0 : 1.0;
-        const double pv1 = (pty < 4) ? mu : 0.0;
-        // --- S2: publish rows pi0 (and pi1) of G; S3: g = G c_p ---
-        {
-          const int r0l = pi0 / T, r0a = pi0 % T, r1l = pi1 / T, r1a = pi1 % T;
-#pragma unroll
-          for (int ta = 0; ta < T; ta++) {
-            if (lr == r0l && ta == r0a) {
-#pragma unroll
-              for (int tb = 0; tb < T; tb++) as_pg[lc * TS + tb] = -(tile[ta][tb] - ((lc == lr && tb == ta) ? 2.0 : 0.0));
-            }
-            if (pv1 != 0.0 && lr == r1l && ta == r1a) {
-#pragma unroll
-              for (int tb = 0; tb < T; tb++) as_pg[NPAD + lc * TS + tb] = -(tile[ta][tb] - ((lc == lr && tb == ta) ? 2.0 : 0.0));
-            }
-          }
-        }
-        __syncthreads();
-        if (owner) {
-          const int ipad = (io / T) * TS + io % T;
-          double gi = pv0 * as_pg[ipad];
-          if (pv1 != 0.0) gi += pv1 * as_pg[NPAD + ipad];
-          as_g[io] = own_real ? gi : 0.0;
-        }
-        __syncthreads();
-        const double sigma = pv0 * as_g[pi0] + pv1 * as_g[pi1];
-        double lam_p = 0.0;
-        // --- inner loop: steps for constraint p until it becomes active (full step) ---
-        bool failed = false;
-        for (int inner = 0; inner < 2 * N + 8; inner++) {
-          // S4: sv = C_A g
+      const int it_cap = 8 * N + 80;
+      bool init = true, failed = false;
+      int passes = 0;
+      for (;; passes++) {
+        if (passes > it_cap) { failed = true; break; }
+        if (init) {
+          if (owner) wpad[iov_pad] = own_real ? qi : 0.0;
+        } else {
+          // S4: sv = C_A g ;  S5: r = T sv (packed symmetric T, row k on lane k)
           if (tid < q) as_sv[tid] = as_v0[tid] * as_g[as_i0[tid]] + as_v1[tid] * as_g[as_i1[tid]];
           __syncthreads();
-          // S5: r = T sv
           if (tid < q) {
             double rk = 0.0;
-            for (int j = 0; j < q; j++) rk = fma(as_T[Tidx(tid, j)], as_sv[j], rk);
+            const int base = tid * (tid + 1) / 2;
+            for (int j = 0; j <= tid; j++) rk = fma(as_T[base + j], as_sv[j], rk);
+            for (int j = tid + 1; j < q; j++) rk = fma(as_T[j * (j + 1) / 2 + tid], as_sv[j], rk);
             as_r[tid] = rk;
           }
           // S6: w = c_p - C_A' r  (dense, padded)
@@ -1105,22 +1055,31 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
             atomicAdd(&wpad[(a0 / T) * TS + a0 % T], -rk * as_v0[tid]);
             if (as_v1[tid] != 0.0) atomicAdd(&wpad[(a1 / T) * TS + a1 % T], -rk * as_v1[tid]);
           }
-          __syncthreads();
-          // S7: z = G w
-          double zz = tile_matvec(wpad);
-          if (!own_real) zz = 0.0;
+        }
+        __syncthreads();
+        double zz = tile_matvec(wpad);   // (G w)_io on owner lanes
+        if (!own_real) zz = 0.0;
+        bool need_search = false;
+        if (init) {
+          x = -zz;
+          if (owner) as_x[io] = x;
+          init = false;
+          need_search = true;
+          __syncthreads();   // x0 must be visible to the search on wave 0
+        } else {
           if (owner) as_z[io] = zz;
-          // S8: step lengths
+          // S8: step lengths (dual bound t1 on wave 0)
           if (tid < 64) {
             double t1 = INFINITY; int lsel = -1;
             for (int kq = tid; kq < q; kq += 64) {
               const double rk = as_r[kq];
               if (rk > 0.0) { const double cand = as_lam[kq] / rk; if (cand < t1) { t1 = cand; lsel = kq; } }
             }
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-              const double ot = __shfl_xor(t1, o); const int ol = __shfl_xor(lsel, o);
-              if (ot < t1 || (ot == t1 && ol >= 0 && (lsel < 0 || ol < lsel))) { t1 = ot; lsel = ol; }
+            {
+              const double tmin = wave_min_f64(t1);
+              const unsigned long long hit = __ballot(t1 == tmin && lsel >= 0);
+              lsel = hit ? __builtin_amdgcn_readlane(lsel, __ffsll((long long)hit) - 1) : -1;
+              t1 = tmin;
             }
             if (tid == 0) { as_sc[2] = t1; as_sc[3] = (double)lsel; }
           }
@@ -1139,14 +1098,18 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
           const bool full = have_z && (t2 <= t1);
           __syncthreads();
           if (full) {
-            // add p: T <- [[T + r r'/dz, -r/dz], [-r'/dz, 1/dz]]
+            // add p: T <- [[T + r r'/dz, -r/dz], [-r'/dz, 1/dz]]   (row i of the packed triangle on lane i)
             const double idz = 1.0 / dz;
-            for (int e = tid; e < q * (q + 1) / 2; e += NT) {
-              int i2 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-              while (i2 * (i2 + 1) / 2 > e) i2--;
-              while ((i2 + 1) * (i2 + 2) / 2 <= e) i2++;
-              const int j2 = e - i2 * (i2 + 1) / 2;
-              as_T[e] = fma(as_r[i2] * idz, as_r[j2], as_T[e]);
+            for (int i2 = tid; i2 < q; i2 += NT) {
+              const double ri = as_r[i2] * idz;
+              double *Trow = as_T + i2 * (i2 + 1) / 2;
+              int j2 = 0;
+              for (; j2 + 3 <= i2; j2 += 4) {   // four independent read-modify-writes in flight
+                const double t0 = Trow[j2], t1_ = Trow[j2 + 1], t2_ = Trow[j2 + 2], t3 = Trow[j2 + 3];
+                const double r0 = as_r[j2], r1 = as_r[j2 + 1], r2 = as_r[j2 + 2], r3 = as_r[j2 + 3];
+                Trow[j2] = fma(ri, r0, t0); Trow[j2 + 1] = fma(ri, r1, t1_); Trow[j2 + 2] = fma(ri, r2, t2_); Trow[j2 + 3] = fma(ri, r3, t3);
+              }
+              for (; j2 <= i2; j2++) Trow[j2] = fma(ri, as_r[j2], Trow[j2]);
             }
             if (tid < q) as_T[q * (q + 1) / 2 + tid] = -as_r[tid] * idz;
             if (tid == 0) {
@@ -1155,30 +1118,34 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
               as_am[pblk] |= 1 << pty;
             }
             q++;
+            it++;
+            need_search = true;
             __syncthreads();
-            break;
-          }
-          // partial step: drop constraint lsel, keep working on p
-          {
-            const int l = lsel;
-            const double tau_l = as_T[Tidx(l, l)];
-            const double itau = 1.0 / tau_l;
-            // column l of T into as_sv (scratch), then downdate all pairs not touching l
-            if (tid < q) as_sv[tid] = as_T[Tidx(tid, l)];
+          } else {
+            // partial step: drop constraint l = lsel (its multiplier reached 0), keep working on p
+            const int l = lsel, last = q - 1;
+            const double itau = 1.0 / as_T[l * (l + 1) / 2 + l];
+            if (tid < q) as_sv[tid] = (tid <= l) ? as_T[l * (l + 1) / 2 + tid] : as_T[tid * (tid + 1) / 2 + l];   // column l
             __syncthreads();
-            for (int e = tid; e < q * (q + 1) / 2; e += NT) {
-              int i2 = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-              while (i2 * (i2 + 1) / 2 > e) i2--;
-              while ((i2 + 1) * (i2 + 2) / 2 <= e) i2++;
-              const int j2 = e - i2 * (i2 + 1) / 2;
-              if (i2 != l && j2 != l) as_T[e] = fma(-as_sv[i2] * itau, as_sv[j2], as_T[e]);
+            for (int i2 = tid; i2 < q; i2 += NT) {
+              if (i2 == l) continue;
+              const double ci = -as_sv[i2] * itau;
+              double *Trow = as_T + i2 * (i2 + 1) / 2;
+              int j2 = 0;
+              for (; j2 + 3 <= i2; j2 += 4) {   // entries in row/column l are dead after the drop: updating them is harmless
+                const double t0 = Trow[j2], t1_ = Trow[j2 + 1], t2_ = Trow[j2 + 2], t3 = Trow[j2 + 3];
+                const double c0 = as_sv[j2], c1_ = as_sv[j2 + 1], c2_ = as_sv[j2 + 2], c3 = as_sv[j2 + 3];
+                Trow[j2] = fma(ci, c0, t0); Trow[j2 + 1] = fma(ci, c1_, t1_); Trow[j2 + 2] = fma(ci, c2_, t2_); Trow[j2 + 3] = fma(ci, c3, t3);
+              }
+              for (; j2 <= i2; j2++) Trow[j2] = fma(ci, as_sv[j2], Trow[j2]);
             }
             __syncthreads();
-            // move the last active constraint into slot l
-            const int last = q - 1;
-            if (l != last) {
-              if (tid < last && tid != l) as_T[Tidx(l, tid)] = as_T[Tidx(last, tid)];
-              if (tid == 0) as_T[Tidx(l, l)] = as_T[Tidx(last, last)];
+            if (l != last) {   // move the last active constraint into slot l
+              if (tid < last && tid != l) {
+                const double v = as_T[last * (last + 1) / 2 + tid];
+                if (tid < l) as_T[l * (l + 1) / 2 + tid] = v; else as_T[tid * (tid + 1) / 2 + l] = v;
+              }
+              if (tid == 0) as_T[l * (l + 1) / 2 + l] = as_T[last * (last + 1) / 2 + last];
             }
             if (tid == 0) {
               const int did = as_id[l];
@@ -1189,9 +1156,62 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
             __syncthreads();
           }
         }
-        if (failed) { if (tid == 0) atomicAdd(&st.counts[7], 1); break; }
+        if (need_search) {
+          // --- S1: most violated inactive constraint (wave 0) ---
+          if (tid < 64) {
+            double best = 0.0; int bid = -1;
+            for (int blk2 = tid; blk2 < NB; blk2 += 64) {
+              const double fx = as_x[3 * blk2], fy = as_x[3 * blk2 + 1], fz = as_x[3 * blk2 + 2];
+              const int am = as_am[blk2];
+              const double sv6[6] = {-fx + mu * fz, fx + mu * fz, -fy + mu * fz, fy + mu * fz, fz - lo, hi - fz};
+#pragma unroll
+              for (int ty = 0; ty < 6; ty++) if (!((am >> ty) & 1) && sv6[ty] < best) { best = sv6[ty]; bid = 6 * blk2 + ty; }
+            }
+            {
+              const double bmin = wave_min_f64(best);
+              const unsigned long long hit = __ballot(best == bmin && bid >= 0);
+              bid = hit ? __builtin_amdgcn_readlane(bid, __ffsll((long long)hit) - 1) : -1;
+              best = bmin;
+            }
+            if (tid == 0) { as_sc[0] = best; as_sc[1] = (double)bid; }
+          }
+          __syncthreads();
+          s_p = as_sc[0];
+          pid = (int)as_sc[1];
+          if (pid < 0 || s_p >= -vtol) break;
+          pblk = pid / 6; pty = pid % 6;
+          pi0 = (pty < 2) ? 3 * pblk : (pty < 4 ? 3 * pblk + 1 : 3 * pblk + 2);
+          pi1 = 3 * pblk + 2;
+          pv0 = (pty == 0 || pty == 2 || pty == 5) ? -1.0 : 1.0;
+          pv1 = (pty < 4) ? mu : 0.0;
+          lam_p = 0.0;
+          // --- S2: publish rows pi0 (and pi1) of G; S3: g = G c_p ---
+          {
+            const int r0l = pi0 / T, r0a = pi0 % T, r1l = pi1 / T, r1a = pi1 % T;
+#pragma unroll
+            for (int ta = 0; ta < T; ta++) {
+              if (lr == r0l && ta == r0a) {
+#pragma unroll
+                for (int tb = 0; tb < T; tb++) as_pg[lc * TS + tb] = -(tile[ta][tb] - ((lc == lr && tb == ta) ? 2.0 : 0.0));
+              }
+              if (pv1 != 0.0 && lr == r1l && ta == r1a) {
+#pragma unroll
+                for (int tb = 0; tb < T; tb++) as_pg[NPAD + lc * TS + tb] = -(tile[ta][tb] - ((lc == lr && tb == ta) ? 2.0 : 0.0));
+              }
+            }
+          }
+          __syncthreads();
+          if (owner) {
+            const int ipad = (io / T) * TS + io % T;
+            double gi = pv0 * as_pg[ipad];
+            if (pv1 != 0.0) gi += pv1 * as_pg[NPAD + ipad];
+            as_g[io] = own_real ? gi : 0.0;
+          }
+          __syncthreads();
+          sigma = pv0 * as_g[pi0] + pv1 * as_g[pi1];
+        }
       }
-      if (it >= it_cap && tid == 0) atomicAdd(&st.counts[7], 1);
+      if (failed && tid == 0) atomicAdd(&st.counts[7], 1);
       z = x;
     } else {
     // ---- over-relaxed ADMM; scalar state lives on the owner lane of each row ----
@@ -1208,6 +1228,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
     double zchk = z;
     int next_chk = chk;
     it = 0;
+    bool converged = false;
     for (; it < c->admm_iters; it++) {
       double acc[T];
       {
@@ -1301,8 +1322,12 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
         const int moving = own_real && fabs(z - zchk) > atol;
         zchk = z;
         next_chk += chk;
-        if (!__syncthreads_or(moving)) { it++; break; }
+        if (!__syncthreads_or(moving)) { it++; converged = true; break; }
       } else __syncthreads();
+    }
+    if (c->solver == RG_SOLVER_AUTO && atol > 0.0 && !converged && tid == 0) {   // hand the robot to the exact solver
+      const int slot = atomicAdd(&st.counts[8 + NC], 1);
+      st.bins[(size_t)(5 + NC) * B + slot] = b;
     }
     }
     if (tid == 0) { atomicAdd(&st.counts[5], it); atomicMax(&st.counts[6], it); }
@@ -1329,7 +1354,7 @@ rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, in
 }
 
 template <int NC, int H, int T, int LG, int MINW, bool AS>
-static hipError_t launch_qp_tile_impl(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s) {
+static hipError_t launch_qp_tile_impl(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s, bool retry) {
   constexpr int m3 = 3 * NC, N = m3 * H, LC = 1 << LG, NP = T * LC, NT = LC * LC;
   constexpr int TS = (T == 8) ? 10 : T, NPAD = TS * LC;
   size_t lds = sizeof(double) * (size_t)(2 * (NPAD + 2) + NPAD + NP + 2 * m3 * m3 + 2 * N + 6 * m3 + RG_REC_N + 24 + 2 * H * H);
@@ -1342,21 +1367,24 @@ static hipError_t launch_qp_tile_impl(const DevCfg *dcfg, const DevState &st, co
     attr_set = lds;
   }
   int grid = cu_count * 8;
+  if (retry) grid = cu_count / 2;   // retry lists are short; a full grid of large-LDS workgroups takes tens of us just to drain
   if (grid > B) grid = B;
-  rg_qp_admm_tile_kernel<NC, H, T, LG, MINW, AS><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B);
+  if (grid < 1) grid = 1;
+  rg_qp_admm_tile_kernel<NC, H, T, LG, MINW, AS><<<dim3(grid), dim3(NT), lds, s>>>(dcfg, st, dout, B, retry ? 1 : 0);
   return hipGetLastError();
 }
 
 template <int NC, int H, int T, int LG, int MINW>
-static hipError_t launch_qp_tile(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s, bool active_set) {
+static hipError_t launch_qp_tile(const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu_count, hipStream_t s, int active_set) {
+  // active_set: 0 = ADMM kernel, 1 = active-set kernel on the main list, 2 = active-set kernel on the retry list
   if (active_set) {
-    if constexpr (H == 10) return launch_qp_tile_impl<NC, H, T, LG, MINW, true>(dcfg, st, dout, B, cu_count, s);
+    if constexpr (H == 10) return launch_qp_tile_impl<NC, H, T, LG, MINW, true>(dcfg, st, dout, B, cu_count, s, active_set == 2);
     else return hipErrorInvalidValue;
   }
-  return launch_qp_tile_impl<NC, H, T, LG, MINW, false>(dcfg, st, dout, B, cu_count, s);
+  return launch_qp_tile_impl<NC, H, T, LG, MINW, false>(dcfg, st, dout, B, cu_count, s, false);
 }
 
-static bool launch_qp_tile_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err, bool active_set) {
+static bool launch_qp_tile_dispatch(int nc, int H, const DevCfg *dcfg, const DevState &st, const DevOut &dout, int B, int cu, hipStream_t s, hipError_t *err, int active_set) {
   *err = hipSuccess;
   if (H == 10) {
     switch (nc) {
@@ -1426,6 +1454,7 @@ struct rg_mpc_handle {
   int prof_max = 0, prof_n = 0;
   bool force_lds_kernel = false;
   int qp_variant = 0;
+  bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
   bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_front = nullptr, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1461,7 +1490,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
-  if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
+  if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
   if (c->solver == RG_SOLVER_ACTIVE_SET && ((c->reserved0 & 7) != 0 || c->horizon != 10 || c->contact_lookahead)) { err = "the active-set solver needs the tiled QP kernel, horizon 10 and no contact look-ahead"; return RG_MPC_ERR_INVALID; }
   if (c->contact_lookahead && ((c->reserved0 & 7) != 0 || (c->horizon != 10 && c->horizon != 20))) { err = "contact_lookahead needs the tiled QP kernel (reserved0 bits 0-2 clear) and horizon 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
@@ -1547,6 +1576,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
   h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
+  h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && cfg->horizon == 10 && !cfg->contact_lookahead;
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
   h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
@@ -1567,7 +1597,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.ring, 3 * W * B); AL(h->st.ring_len, B); AL(h->st.ring_head, B);
   AL(h->st.fsum, 3 * B); AL(h->st.fcorr, 3 * B);
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
-  AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N); AL(h->st.bins, 5 * B); AL(h->st.counts, 8);
+  AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N); AL(h->st.bins, 10 * B); AL(h->st.counts, 16);
   AL(h->idx_dev, B); AL(h->t0_dev, B);
   CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
   for (int nc = 1; nc <= 4; nc++) {
@@ -1655,7 +1685,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   const int B = h->B, H = h->cfg.horizon;
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
-  HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 8, s));
+  HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 16, s));
   hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, s, h->dcfg, h->st, di, dout, t, B);
@@ -1676,9 +1706,13 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     bool launched = false;
     if (!h->force_lds_kernel && h->qp_variant != 2 && h->qp_variant != 1) {
       hipError_t lerr;
-      if (launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, h->cfg.solver == RG_SOLVER_ACTIVE_SET)) {
+      if (launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 1 : 0)) {
         HIPCHK(h, lerr);
         launched = true;
+        if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) {   // exact re-solve of the robots ADMM left unconverged
+          launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, 2);
+          HIPCHK(h, lerr);
+        }
       }
     }
     if (!launched && !h->force_lds_kernel) {
@@ -1749,15 +1783,18 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
   return RG_MPC_OK;
 }
 
-int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots, void *stream) {
+int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
+                             int32_t *retried, int32_t *failures, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-  int cnt[8];
+  int cnt[16];
   HIPCHK(h, hipMemcpy(cnt, h->st.counts, sizeof(cnt), hipMemcpyDeviceToHost));
   if (iters_sum) *iters_sum = cnt[5];
   if (iters_max) *iters_max = cnt[6];
   if (qp_robots) *qp_robots = cnt[1] + cnt[2] + cnt[3] + cnt[4];
+  if (retried) *retried = cnt[9] + cnt[10] + cnt[11] + cnt[12];
+  if (failures) *failures = cnt[7];
   return RG_MPC_OK;
 }
 

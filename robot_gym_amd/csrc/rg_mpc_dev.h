@@ -63,8 +63,8 @@ struct DevState {
   int *swing_valid;     // [B] 12-bit mask
   float *cmd;           // [3][B] rg_mpc_set_command copy
   double *rec;          // [B][RG_REC_N]
-  int *bins;            // [5][B]
-  int *counts;          // [8]: [0..4] robots per stance count, [5] sum of ADMM iterations, [6] max, [7] spare
+  int *bins;            // [10][B]: [0..4] robots per stance count, [5..9] retry lists for the active-set pass
+  int *counts;          // [16]: [0..4] robots per stance count, [5] sum of solver iterations, [6] max, [7] failures, [8..12] retry-list lengths
 };
 
 struct DevIn {
@@ -199,6 +199,27 @@ __device__ __forceinline__ double dpp_f64(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_masked(double x) {   // lanes outside ROW_MASK keep x
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Minimum over the 64 lanes of a wave, all in DPP + readlane (an LDS butterfly costs six dependent
+// ds_bpermute round trips).  Every lane gets the result.
+__device__ __forceinline__ double wave_min_f64(double v) {
+  v = fmin(v, dpp_f64<0xB1>(v));             // lane ^ 1
+  v = fmin(v, dpp_f64<0x4E>(v));             // lane ^ 2
+  v = fmin(v, dpp_f64<0x141>(v));            // 7 - i  : 8 lanes
+  v = fmin(v, dpp_f64<0x140>(v));            // 15 - i : 16 lanes
+  v = fmin(v, dpp_f64_masked<0x142, 0xA>(v)); // row_bcast15 into rows 1, 3
+  v = fmin(v, dpp_f64_masked<0x143, 0xC>(v)); // row_bcast31 into rows 2, 3
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
 

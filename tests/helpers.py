@@ -91,6 +91,7 @@ def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0"
         for kx, v in ctl.extra.items():
             o[kx] = v.cpu().numpy().copy()
         o["bins"] = ctl.bin_counts()
+        o["solver_stats"] = ctl.solver_stats()
         outs.append(o)
     ctl.close()
     return outs

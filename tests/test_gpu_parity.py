@@ -106,3 +106,31 @@ def test_contact_lookahead_extension(oracle_lib, horizon):
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=8, jitter=0.1)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=8, jitter=0.1)
     _check(gpu, orc)
+
+
+@pytest.mark.parametrize("solver", [1, 2])   # 1 = exact active set, 2 = ADMM with exact retry (default)
+@pytest.mark.parametrize("gait", ["pace", "bound"])
+def test_statically_unbalanced_gaits(oracle_lib, gait, solver):
+    """Lateral (pace) and fore/hind (bound) leg pairs cannot balance the body: many constraints are active
+    in stiff directions and fixed-rho ADMM does not converge (errors > 1 after 1000 iterations).  The
+    exact active-set kernel, alone or as the retry pass of the default solver, must still match the oracle."""
+    phases = {"pace": (0.0, 0.5, 0.0, 0.5), "bound": (0.0, 0.0, 0.5, 0.5)}[gait]
+    cfg = MPCConfig.for_robot("ghost", duty_factor=(0.55,) * 4, init_phase=phases, init_state=(1, 1, 1, 1), solver=solver)
+    state, cmd, t_off = synthetic.make_states(160, cfg, seed=3)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=4, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=4, jitter=0.1)
+    _check(gpu, orc)
+    stats = gpu[-1]["solver_stats"]
+    assert stats["failures"] == 0
+    if solver == 2:
+        assert stats["retried_exact"] > 0   # the fallback is what makes these cases pass
+
+
+def test_exact_solver_on_standard_trot(oracle_lib):
+    cfg = MPCConfig.for_robot("ghost", solver=1)
+    state, cmd, t_off = synthetic.make_states(256, cfg, seed=13)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    for g, o in zip(gpu, orc):
+        m = helpers.compare_tick(g, o)
+        assert m["tau_rel_max"] <= 1e-6 and m["grf_rel_max"] <= 1e-6 and m["leg_state_mismatch"] == 0, m   # float32 output rounding only
