@@ -771,7 +771,7 @@ __device__ __forceinline__ int bitrev_lt(int x) {
 }
 
 template <int NC, int H, int T, int LG, int MINW, bool AS>
-__global__ void __launch_bounds__((1 << LG) * (1 << LG), MINW)
+__global__ void __launch_bounds__((1 << LG) * (1 << LG), AS ? 1 : MINW)
 rg_qp_admm_tile_kernel(const DevCfg *__restrict__ c, DevState st, DevOut out, int B, int retry_pass) {
   constexpr int m3 = 3 * NC;
   constexpr int N = m3 * H;          // real QP variables
