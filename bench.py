@@ -50,7 +50,7 @@ def traffic_from_profile(kernel_name, batch):
             return None
         nc = kernel_name.split("nc=")[1][0] if "nc=" in kernel_name else None
         for k, v in prof["traffic"].items():
-            if (nc and f"tile_kernel<{nc}," in k) or (nc is None and "front" in k):
+            if (nc and f"tile_kernel<{nc}," in k and "true>" not in k) or (nc is None and "front" in k):
                 return v["hbm_bytes_per_launch"]
     except Exception:
         pass
