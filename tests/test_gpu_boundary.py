@@ -235,3 +235,26 @@ def test_parity_at_baseline_batch_4096(oracle_lib):
         assert m["tau_rel_max"] <= 1e-4 and m["grf_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, m
         worst = max(worst, m["tau_rel_max"])
     print("worst relative torque error over 8192 robot-ticks:", worst)
+
+
+def test_step_argument_validation_reports_errors():
+    """Bad calls come back as RgMpcError with the library's message (status codes never leak as crashes)."""
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    from robot_gym_amd.core.mpc_abi import RgMpcError
+    cfg = MPCConfig.for_robot("ghost")
+    state, cmd, t_off = synthetic.make_states(8, cfg, seed=1)
+    ctl = BatchedMPCController(8, cfg)
+    dev = {n: torch.from_numpy(np.ascontiguousarray(state[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+    dev["contact"] = torch.ones(4, 8, dtype=torch.int32, device="cuda")
+    ctl.update_controller_params(torch.zeros(8, 3))
+    with pytest.raises(KeyError):
+        ctl.get_action(0.0, {k: v for k, v in dev.items() if k != "jac"})          # kin_mode 0 needs Jacobians
+    with pytest.raises(ValueError):
+        ctl.get_action(0.0, dict(dev, rpy=dev["rpy"].double()))                    # wrong dtype
+    with pytest.raises(ValueError):
+        ctl.update_controller_params(torch.zeros(8, 4))                             # (vx, wz) or (vx, vy, wz) only
+    with pytest.raises(RgMpcError):
+        ctl._handle.reset([99], 0.0)                                                # index out of range
+    act = ctl.get_action(0.0, dev)                                                  # still usable afterwards
+    assert torch.isfinite(act).all()
+    ctl.close()
