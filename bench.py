@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
     ap.add_argument("--solver", type=int, default=None, help="0 = ADMM, 1 = exact active set")
+    ap.add_argument("--warm-start", action="store_true", help="opt-in ADMM warm start from the previous tick (not the headline configuration)")
     ap.add_argument("--cap", type=int, default=None, help="ADMM iteration cap (keeps the convergence test)")
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
@@ -126,6 +127,8 @@ def main():
         over["solver"] = args.solver
     if args.cap is not None:
         over["admm_iters"] = args.cap
+    if args.warm_start:
+        over["warm_start"] = 1
     if args.rho is not None:
         over["admm_rho"] = args.rho
     if args.relax is not None:
@@ -200,7 +203,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batch={B} quadrupeds per GPU, horizon={HORIZON}, randomised (vx,vy,wz) commands (BASELINE configs[2])",
                        "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}", "admm_iterations": stats,
-                       "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
+                       "warm_start": bool(cfg.warm_start), "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
                        "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(names[dom], B),

@@ -103,6 +103,9 @@ typedef struct {
   int32_t admm_check;       /* convergence check period (10) */
   int32_t contact_lookahead;/* EXTENSION (not in upstream, default 0): horizon step k uses the open-loop desired contact
                                state at t + k*dt_plan instead of holding the current contacts */
+  int32_t warm_start;       /* opt-in (default 0): start ADMM from the robot's previous-tick (z, y) when its contact set is
+                               unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve */
+  int32_t reserved2;
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per

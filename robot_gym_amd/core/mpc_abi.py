@@ -33,7 +33,7 @@ class CConfig(C.Structure):
         ("motor_off", d * 12), ("jxyz", d * 36), ("jrpy", d * 36), ("jaxis", d * 36), ("toe_xyz", d * 12),
         ("toe_com", d * 12), ("base_com", d * 3), ("ik_iters", i32), ("solver", i32), ("ik_damping", d),
         ("ik_max_step", d), ("admm_iters", i32), ("reserved0", i32), ("admm_rho", d), ("admm_relax", d),
-        ("admm_tol", d), ("admm_check", i32), ("contact_lookahead", i32),
+        ("admm_tol", d), ("admm_check", i32), ("contact_lookahead", i32), ("warm_start", i32), ("reserved2", i32),
     ]
 
 
@@ -103,7 +103,7 @@ def make_cconfig(cfg):
     c = CConfig()
     c.abi_version = ABI_VERSION
     for name, ctype in CConfig._fields_:
-        if name in ("abi_version",):
+        if name in ("abi_version", "reserved2"):
             continue
         v = getattr(cfg, name)
         if isinstance(v, (tuple, list)) or hasattr(v, "__len__"):

@@ -39,6 +39,7 @@ __global__ void rg_reset_kernel(const DevCfg *__restrict__ c, DevState st, const
   st.ring_len[b] = 0; st.ring_head[b] = 0;
   for (int a = 0; a < 3; a++) { st.fsum[a * B + b] = 0.0; st.fcorr[a * B + b] = 0.0; }
   st.swing_valid[b] = 0;
+  st.warm_key[b] = -1;
 }
 
 // RobotMotorModel.convert_to_torque HYBRID (reference model/robots/simple_motor.py:128-140)
@@ -151,7 +152,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
   d->rho = c->admm_rho; d->relax = c->admm_relax;
-  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver;
+  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
     for (int b = 0; b < H; b++) {
@@ -216,7 +217,9 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.ring, 3 * W * B); AL(h->st.ring_len, B); AL(h->st.ring_head, B);
   AL(h->st.fsum, 3 * B); AL(h->st.fcorr, 3 * B);
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
-  AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N); AL(h->st.bins, 10 * B); AL(h->st.counts, 16);
+  AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N);
+  if (cfg->warm_start) { AL(h->st.warm_z, B * RG_WARM_N); AL(h->st.warm_y, B * RG_WARM_N); }
+  AL(h->st.warm_key, B); AL(h->st.bins, 10 * B); AL(h->st.counts, 16);
   AL(h->idx_dev, B); AL(h->t0_dev, B);
   CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
   for (int nc = 1; nc <= 4; nc++) {

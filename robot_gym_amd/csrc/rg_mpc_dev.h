@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #define RG_MAXH 20
+#define RG_WARM_N 256 // doubles per robot for the stored ADMM iterate (n <= 240)
 #define RG_REC_N 96  // doubles per robot in the front->QP record
 
 // record layout (doubles)
@@ -46,7 +47,7 @@ struct DevCfg {
   double rho, relax;
   double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count)
   int admm_check, lookahead;
-  int solver, pad2;
+  int solver, warm;
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };
@@ -63,6 +64,8 @@ struct DevState {
   int *swing_valid;     // [B] 12-bit mask
   float *cmd;           // [3][B] rg_mpc_set_command copy
   double *rec;          // [B][RG_REC_N]
+  double *warm_z, *warm_y;  // [B][RG_WARM_N] previous-tick ADMM iterate (warm start)
+  int *warm_key;        // [B] contact mask the stored iterate belongs to (-1 = none)
   int *bins;            // [10][B]: [0..4] robots per stance count, [5..9] retry lists for the active-set pass
   int *counts;          // [16]: [0..4] robots per stance count, [5] sum of solver iterations, [6] max, [7] failures, [8..12] retry-list lengths
 };

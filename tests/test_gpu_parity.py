@@ -134,3 +134,17 @@ def test_exact_solver_on_standard_trot(oracle_lib):
     for g, o in zip(gpu, orc):
         m = helpers.compare_tick(g, o)
         assert m["tau_rel_max"] <= 1e-6 and m["grf_rel_max"] <= 1e-6 and m["leg_state_mismatch"] == 0, m   # float32 output rounding only
+
+
+def test_warm_start_stays_within_tolerance(oracle_lib):
+    """Opt-in warm start: ADMM starts from the previous tick's iterate when the contact set is unchanged.
+    Same tolerance as the cold solve; fewer iterations on slowly changing states."""
+    cfg = MPCConfig.for_robot("ghost", warm_start=1)
+    state, cmd, t_off = synthetic.make_states(192, cfg, seed=15)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=30, jitter=0.05)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=30, jitter=0.05)
+    _check(gpu, orc)
+    cold = helpers.run_gpu(MPCConfig.for_robot("ghost"), state, cmd, t_off, ticks=30, jitter=0.05)
+    it_warm = np.mean([g["solver_stats"]["iters_mean"] for g in gpu[5:]])
+    it_cold = np.mean([g["solver_stats"]["iters_mean"] for g in cold[5:]])
+    assert it_warm < 0.8 * it_cold, (it_warm, it_cold)
