@@ -63,7 +63,7 @@ def cpu_baseline(cfg, budget_s=12.0):
     from tests import helpers
     from robot_gym_amd import synthetic
     cores = os.cpu_count() or 1
-    Bs = 512
+    Bs = 2048
     state, cmd, t_off = synthetic.make_states(Bs, cfg, seed=0)
     ocfg = helpers.oracle_config(O, cfg)
     ob = O.OracleBatch(ocfg, Bs, 0.0, cores)

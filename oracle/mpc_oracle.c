@@ -740,7 +740,7 @@ int orc_step_batch(const orc_config *c, orc_state *s, int B, double t_now, const
 #else
   (void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 8) reduction(+ : bad)
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : bad)
   for (int b = 0; b < B; b++) if (orc_step(c, &s[b], t_now, &in[b], &out[b])) bad++;
   return bad;
 }
