@@ -57,7 +57,7 @@ def traffic_from_profile(kernel_name, batch):
     return None
 
 
-def cpu_baseline(cfg, budget_s=12.0):
+def cpu_baseline(cfg, budget_s=10.0):
     """Time the oracle (port) on the host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
     from tests import helpers
@@ -66,12 +66,28 @@ def cpu_baseline(cfg, budget_s=12.0):
     Bs = 2048
     state, cmd, t_off = synthetic.make_states(Bs, cfg, seed=0)
     ocfg = helpers.oracle_config(O, cfg)
-    ob = O.OracleBatch(ocfg, Bs, 0.0, cores)
-    for b in range(Bs):
-        ob.states[b].reset_time = -float(t_off[b])
     coff = helpers.cmd_with_offsets(cfg, cmd)
     contact = synthetic.gait_consistent_contacts(cfg, t_off, state["_flip"])
     inp = helpers.oracle_inputs(O, state, coff, contact)
+
+    def fresh(nthreads):
+        ob = O.OracleBatch(ocfg, Bs, 0.0, nthreads)
+        for b in range(Bs):
+            ob.states[b].reset_time = -float(t_off[b])
+        return ob
+
+    # the port allocates per step; on many-core hosts fewer threads can be faster -> pick the best count first
+    best_threads, best_rate = cores, 0.0
+    for nthreads in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+        ob = fresh(nthreads)
+        ob.step(0.0, inp)
+        t0 = time.perf_counter()
+        ob.step(0.01, inp)
+        rate = Bs / (time.perf_counter() - t0)
+        if rate > best_rate:
+            best_threads, best_rate = nthreads, rate
+    cores = best_threads
+    ob = fresh(cores)
     ob.step(0.0, inp)  # warm
     t0 = time.perf_counter()
     ticks = 0
