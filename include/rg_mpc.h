@@ -143,7 +143,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
 /* LocomotionController.reset() (via MPCController.reset, mpc_controller.py:108-109) for the
  * robots idx[0..n) (HOST pointer; NULL = all).  t0 = clock value at reset
  * (core/simulation.py:141-142).  Swing start positions are latched from the foot positions
- * of the first rg_mpc_step after the reset. */
+ * of the first rg_mpc_step after the reset.  With an index list the call waits for its own small
+ * host->device copy (the staging buffer is reused); with idx_host == NULL it is fully asynchronous. */
 int rg_mpc_reset(rg_mpc_handle *h, const int32_t *idx_host, int32_t n, double t0, void *stream);
 
 /* Same, with one clock value per robot: t0_host[k] applies to idx_host[k] (idx NULL = robots
