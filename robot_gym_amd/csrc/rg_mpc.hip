@@ -22,6 +22,7 @@
 #include "rg_qp_lds_kernel.inc"
 #include "rg_qp_row_kernel.inc"
 #include "rg_qp_tile_kernel.inc"
+#include "rg_qp_wrench_kernel.inc"
 
 // ------------------------------------------------------------------------------------
 // small kernels
@@ -74,6 +75,7 @@ struct rg_mpc_handle {
   int prof_max = 0, prof_n = 0;
   bool force_lds_kernel = false;
   int qp_variant = 0;
+  bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
   bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
   bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -186,7 +188,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_tile_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_tile_kernel,rg_qp_wrench_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -198,6 +200,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
   h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && cfg->horizon == 10 && !cfg->contact_lookahead;
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
+  h->wrench_space = ((cfg->reserved0 >> 4) & 1) == 0;
   h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   if (rc) { g_create_err = h->err; delete h; return rc; }
@@ -328,7 +331,9 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     bool launched = false;
     if (!h->force_lds_kernel && h->qp_variant != 2 && h->qp_variant != 1) {
       hipError_t lerr;
-      if (launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 1 : 0)) {
+      const bool exact = h->cfg.solver == RG_SOLVER_ACTIVE_SET;
+      if ((!exact && h->wrench_space && launch_qp_wrench_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr)) ||
+          launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, exact ? 1 : 0)) {
         HIPCHK(h, lerr);
         launched = true;
         if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) {   // exact re-solve of the robots ADMM left unconverged
