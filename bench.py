@@ -50,7 +50,7 @@ def traffic_from_profile(kernel_name, batch):
             return None
         nc = kernel_name.split("nc=")[1][0] if "nc=" in kernel_name else None
         for k, v in prof["traffic"].items():
-            if (nc and f"tile_kernel<{nc}," in k and "true>" not in k) or (nc is None and "front" in k):
+            if (nc and f"tile_kernel<{nc}," in k and "true>" not in k) or (nc is None and kernel_name.split("<")[0] in k):
                 return v["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -207,8 +207,12 @@ def main():
     if rank == 0:
         total_units = world * B * args.steps
         value = total_units / elapsed
-        names = ["rg_front_kernel", "rg_qp_admm_tile_kernel<nc=1>", "rg_qp_admm_tile_kernel<nc=2>", "rg_qp_admm_tile_kernel<nc=3>", "rg_qp_admm_tile_kernel<nc=4>"]
-        units = [B, robots[1], robots[2], robots[3], robots[4]]
+        wn = ctl._handle.profile_window_names()
+        names = wn[:5]
+        if "fused" in wn[1]:   # one QP launch over all stance-leg counts, then the exact re-solve launches
+            units = [B, robots[1] + robots[2] + robots[3] + robots[4], stats["retried_exact"], 0, 0]
+        else:
+            units = [B, robots[1], robots[2], robots[3], robots[4]]
         dom = int(np.argmax(kms[:5]))
         dur_s = kms[dom] * 1e-3
         achieved = (ALGO_BYTES_PER_STEP * units[dom] / dur_s) / 1e9 if dur_s > 0 else 0.0
@@ -225,7 +229,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(names[dom], B),
                          "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,
                          "avg_launch_ms": kms[dom],
-                         "kernel_ms": dict(zip(names + ["step_total"], [round(x, 4) for x in kms])),
+                         "kernel_ms": {n: round(x, 4) for n, x in zip(names + ["step_total"], kms) if n != "-"},
+                         "robots_per_stance_count": robots,
                          "note": "path is LDS/latency-bound, not HBM-bound (SURVEY.md 7.3-2); see DESIGN.md section 5 for the FLOP/LDS view"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -180,6 +180,14 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
 int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps);
 int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void *stream);
 
+/* Test hook: overwrite the LDS of every CU with NaN bit patterns before the next rg_mpc_step, so reads of
+ * never-written LDS show up deterministically in the parity tests. */
+int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream);
+
+/* Comma-separated labels of the six avg_ms windows for this handle's launch plan (horizon 10 with the
+ * ADMM solver uses one fused QP launch: {front, fused QP, exact re-solves, -, -, whole step}). */
+const char *rg_mpc_profile_window_names(const rg_mpc_handle *h);
+
 /* Names of the kernels launched by rg_mpc_step, for matching rocprof rows. */
 const char *rg_mpc_kernel_names(void);
 

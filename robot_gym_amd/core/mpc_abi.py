@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
-LIB_PATH = os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
+# RG_MPC_LIB: load another build of the same C-ABI (kernel A/B experiments); never a fallback
+LIB_PATH = os.environ.get("RG_MPC_LIB") or os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
 
 ABI_VERSION = 1
 d = C.c_double
@@ -46,7 +47,7 @@ class COutPtrs(C.Structure):
 
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
-           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_profile_begin", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_profile_begin", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -83,6 +84,10 @@ def load_library(path=None):
     L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
     L.rg_mpc_profile_end.restype = i32
     L.rg_mpc_kernel_names.restype = C.c_char_p
+    L.rg_mpc_debug_poison_lds.argtypes = [fp, fp]
+    L.rg_mpc_debug_poison_lds.restype = i32
+    L.rg_mpc_profile_window_names.argtypes = [C.c_void_p]
+    L.rg_mpc_profile_window_names.restype = C.c_char_p
     L.rg_mpc_destroy.argtypes = [fp]
     L.rg_mpc_destroy.restype = None
     L.rg_mpc_last_error.argtypes = [fp]
@@ -179,6 +184,12 @@ class MpcHandle:
         if n < 0:
             self._check(n)
         return n, list(ms), list(rb)
+
+    def debug_poison_lds(self, stream=None):
+        self._check(self._lib.rg_mpc_debug_poison_lds(self._h, stream))
+
+    def profile_window_names(self):
+        return self._lib.rg_mpc_profile_window_names(self._h).decode().split(",")
 
     def kernel_names(self):
         return self._lib.rg_mpc_kernel_names().decode().split(",")

@@ -23,6 +23,7 @@
 #include "rg_qp_row_kernel.inc"
 #include "rg_qp_tile_kernel.inc"
 #include "rg_qp_wrench_kernel.inc"
+#include "rg_qp_fused_kernel.inc"
 
 // ------------------------------------------------------------------------------------
 // small kernels
@@ -76,6 +77,8 @@ struct rg_mpc_handle {
   bool force_lds_kernel = false;
   int qp_variant = 0;
   bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
+  bool fused = false;               // H = 10 ADMM: one launch for all stance-leg counts (reserved0 bit5 = per-bin launches, A/B)
+  bool grid_per_robot = true;       // fused launch: one workgroup per robot, longest first (reserved0 bit6 = 8 workgroups per CU looping, A/B: 3 % slower)
   bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
   bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -188,7 +191,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_admm_tile_kernel,rg_qp_wrench_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_admm_tile_kernel,rg_qp_wrench_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -201,6 +204,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && cfg->horizon == 10 && !cfg->contact_lookahead;
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
   h->wrench_space = ((cfg->reserved0 >> 4) & 1) == 0;
+  h->fused = h->wrench_space && ((cfg->reserved0 >> 5) & 1) == 0 && (cfg->reserved0 & 15) == 0 && cfg->horizon == 10 && cfg->solver != RG_SOLVER_ACTIVE_SET;
+  h->grid_per_robot = ((cfg->reserved0 >> 6) & 1) == 0;
   h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   if (rc) { g_create_err = h->err; delete h; return rc; }
@@ -319,6 +324,25 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // Robots with different stance-leg counts are independent; optionally (reserved0 bit3) the four QP
   // launches are forked onto internal streams and joined back into the caller's stream.  Measured
   // on MI355X this is ~8 % slower than back-to-back launches, so it is off by default.
+  if (h->fused) {
+    // horizon 10, ADMM: one launch over all stance-leg counts, then the (normally empty) exact re-solves
+    if (pev) HIPCHK(h, hipEventRecord(pev[2], s));
+    HIPCHK(h, launch_qp_fused_h10(h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
+    if (pev) { HIPCHK(h, hipEventRecord(pev[3], s)); HIPCHK(h, hipEventRecord(pev[4], s)); }
+    if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) {
+      for (int nc = 4; nc >= 1; nc--) {
+        hipError_t lerr;
+        launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2);
+        HIPCHK(h, lerr);
+      }
+    }
+    if (pev) {
+      HIPCHK(h, hipEventRecord(pev[5], s));
+      for (int k = 6; k <= 10; k++) HIPCHK(h, hipEventRecord(pev[k], s));
+      h->prof_n++;
+    }
+    return RG_MPC_OK;
+  }
   const bool fork = h->concurrent_bins;
   if (fork) HIPCHK(h, hipEventRecord(h->ev_front, s));
   const int order[4] = {4, 2, 3, 1};  // longest first
@@ -382,6 +406,11 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
   return RG_MPC_OK;
 }
 
+const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
+  if (h && h->fused) return "rg_front_kernel,rg_qp_fused_kernel,exact re-solve launches,-,-,step_total";
+  return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
+}
+
 int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void *stream) {
   if (!h || !avg_ms6) { if (h) h->err = "profile_end: null output"; return RG_MPC_ERR_INVALID; }
   HIPCHK(h, hipSetDevice(h->device));
@@ -399,6 +428,25 @@ int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void 
   for (int j = 0; j < 6; j++) avg_ms6[j] = n > 0 ? (float)(acc[j] / n) : 0.f;
   if (robots5) HIPCHK(h, hipMemcpy(robots5, h->st.counts, sizeof(int) * 5, hipMemcpyDeviceToHost));
   return n;
+}
+
+// Test hook: fill the LDS of every CU with NaN bit patterns (LDS keeps its contents between kernels), so a
+// kernel that reads LDS it never wrote fails deterministically instead of once in a while.
+__global__ void rg_debug_poison_lds_kernel(int ndoubles) {
+  for (int e = threadIdx.x; e < ndoubles; e += blockDim.x) smem[e] = __longlong_as_double(0x7ff8dead0000beefLL);
+  __syncthreads();
+  if (smem[(threadIdx.x * 7) % ndoubles] == 0.0) smem[0] = 1.0;   // keep the stores observable
+}
+
+int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream) {
+  if (!h) return RG_MPC_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int bytes = 160 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)rg_debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); attr_set = true; }
+  rg_debug_poison_lds_kernel<<<dim3(h->cu_count * 4), dim3(256), bytes, (hipStream_t)stream>>>(bytes / 8);
+  HIPCHK(h, hipGetLastError());
+  return RG_MPC_OK;
 }
 
 int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream) {

@@ -85,6 +85,7 @@ def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0"
         contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"])
         dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).to(device) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
         dev["contact"] = torch.from_numpy(contact).to(device)
+        ctl._handle.debug_poison_lds(ctl._stream())   # NaN bits in every CU's LDS: reads of unwritten LDS fail every time
         act = ctl.get_action(t, dev)
         torch.cuda.synchronize()
         o = {"action": act.cpu().numpy().copy()}
