@@ -15,7 +15,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("rg_front_kernel", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2", "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4",
+    for k in ("rg_front_kernel", "rg_qp_fused_kernel", "rg_qp_wrench_kernel<3", "rg_qp_wrench_kernel<4", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2", "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4",
               "rg_qp_admm_reg_kernel<1", "rg_qp_admm_reg_kernel<2", "rg_qp_admm_reg_kernel<3", "rg_qp_admm_reg_kernel<4",
               "rg_qp_admm_kernel", "rg_reset_kernel", "rg_hybrid"):
         if k in name:
@@ -33,7 +33,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
             k = short(r["Kernel_Name"])
             if k is None:
                 continue
-            if int(r["Grid_Size"]) <= 8192 and "front" not in k and "reset" not in k:   # empty-bin launches
+            if int(r["Grid_Size"]) <= 8192 and ("false>" in k or "wrench" in k or "reg_kernel" in k):   # empty-bin launches of the per-bin plan
                 continue
             pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
