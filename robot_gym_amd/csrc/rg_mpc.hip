@@ -227,7 +227,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
   AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N);
   if (cfg->warm_start) { AL(h->st.warm_z, B * RG_WARM_N); AL(h->st.warm_y, B * RG_WARM_N); }
-  AL(h->st.warm_key, B); AL(h->st.bins, 10 * B); AL(h->st.counts, 16);
+  AL(h->st.warm_key, B); AL(h->st.bins, 10 * B); AL(h->st.counts, 16); AL(h->st.iters, B);
   AL(h->idx_dev, B); AL(h->t0_dev, B);
   CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
   for (int nc = 1; nc <= 4; nc++) {
@@ -318,7 +318,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 16, s));
   hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
-  hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 255) / 256), dim3(256), 0, s, h->dcfg, h->st, di, dout, t, B);
+  hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);   // one wave per workgroup: 16 k lanes spread over all CUs
   HIPCHK(h, hipGetLastError());
   if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
   // Robots with different stance-leg counts are independent; optionally (reserved0 bit3) the four QP
@@ -465,8 +465,14 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
   int cnt[16];
   HIPCHK(h, hipMemcpy(cnt, h->st.counts, sizeof(cnt), hipMemcpyDeviceToHost));
-  if (iters_sum) *iters_sum = cnt[5];
-  if (iters_max) *iters_max = cnt[6];
+  if (iters_sum || iters_max) {   // per-robot iteration counts, reduced here (the kernels keep no global atomics for them)
+    std::vector<int> it((size_t)h->B);
+    HIPCHK(h, hipMemcpy(it.data(), h->st.iters, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
+    int64_t sum = 0; int mx = 0;
+    for (int v : it) { sum += v; if (v > mx) mx = v; }
+    if (iters_sum) *iters_sum = sum;
+    if (iters_max) *iters_max = mx;
+  }
   if (qp_robots) *qp_robots = cnt[1] + cnt[2] + cnt[3] + cnt[4];
   if (retried) *retried = cnt[9] + cnt[10] + cnt[11] + cnt[12];
   if (failures) *failures = cnt[7];

@@ -67,7 +67,8 @@ struct DevState {
   double *warm_z, *warm_y;  // [B][RG_WARM_N] previous-tick ADMM iterate (warm start)
   int *warm_key;        // [B] contact mask the stored iterate belongs to (-1 = none)
   int *bins;            // [10][B]: [0..4] robots per stance count, [5..9] retry lists for the active-set pass
-  int *counts;          // [16]: [0..4] robots per stance count, [5] sum of solver iterations, [6] max, [7] failures, [8..12] retry-list lengths
+  int *counts;          // [16]: [0..4] robots per stance count, [7] failures, [8..12] retry-list lengths
+  int *iters;           // [B] solver iterations of the last tick (ADMM, plus the exact re-solve's if it ran)
 };
 
 struct DevIn {
@@ -161,6 +162,8 @@ __device__ inline void leg_ik(const DevCfg *c, int leg, const double target[3], 
       for (int j = 0; j < 3; j++) J[3 * i + j] *= c->mdir[3 * leg + j];
 #pragma unroll
     for (int i = 0; i < 3; i++) e[i] = target[i] - p[i];
+    // converged to 1e-12 m: the remaining fixed-count iterations of the CPU arithmetic move q by < 1e-11 rad
+    if (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] < 1e-24) break;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
