@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
     ap.add_argument("--tol", type=float, default=None)
+    ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region (roofline.kernel_ms is then empty)")
     ap.add_argument("--reserved0", type=int, default=0, help="tuning bits passed to rg_mpc_config.reserved0")
     args = ap.parse_args()
 
@@ -171,7 +172,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ctl._handle.profile_begin(args.steps)
+    if not args.no_kernel_events:
+        ctl._handle.profile_begin(args.steps)
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k)

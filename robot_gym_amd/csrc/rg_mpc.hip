@@ -79,6 +79,7 @@ struct rg_mpc_handle {
   bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
   bool fused = false;               // H = 10 ADMM: one launch for all stance-leg counts (reserved0 bit5 = per-bin launches, A/B)
   bool grid_per_robot = true;       // fused launch: one workgroup per robot, longest first (reserved0 bit6 = 8 workgroups per CU looping, A/B: 3 % slower)
+  int *counts2 = nullptr;           // [2][16] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
   bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -191,7 +192,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_admm_tile_kernel,rg_qp_wrench_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,rg_qp_admm_tile_kernel,rg_qp_wrench_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -227,7 +228,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
   AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N);
   if (cfg->warm_start) { AL(h->st.warm_z, B * RG_WARM_N); AL(h->st.warm_y, B * RG_WARM_N); }
-  AL(h->st.warm_key, B); AL(h->st.bins, 10 * B); AL(h->st.counts, 16); AL(h->st.iters, B);
+  AL(h->st.warm_key, B); AL(h->st.bins, 10 * B); AL(h->counts2, 32); AL(h->st.iters, B);
+  h->st.counts = h->counts2; h->st.counts_next = h->counts2 + 16;
   AL(h->idx_dev, B); AL(h->t0_dev, B);
   CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
   for (int nc = 1; nc <= 4; nc++) {
@@ -315,7 +317,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   const int B = h->B, H = h->cfg.horizon;
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
-  HIPCHK(h, hipMemsetAsync(h->st.counts, 0, sizeof(int) * 16, s));
+  { int *t_ = h->st.counts; h->st.counts = h->st.counts_next; h->st.counts_next = t_; }   // this tick's counters were zeroed by the previous tick's front kernel
   hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);   // one wave per workgroup: 16 k lanes spread over all CUs
@@ -329,13 +331,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     if (pev) HIPCHK(h, hipEventRecord(pev[2], s));
     HIPCHK(h, launch_qp_fused_h10(h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
     if (pev) { HIPCHK(h, hipEventRecord(pev[3], s)); HIPCHK(h, hipEventRecord(pev[4], s)); }
-    if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) {
-      for (int nc = 4; nc >= 1; nc--) {
-        hipError_t lerr;
-        launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2);
-        HIPCHK(h, lerr);
-      }
-    }
+    if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) {
       HIPCHK(h, hipEventRecord(pev[5], s));
       for (int k = 6; k <= 10; k++) HIPCHK(h, hipEventRecord(pev[k], s));
@@ -407,7 +403,7 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
 }
 
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
-  if (h && h->fused) return "rg_front_kernel,rg_qp_fused_kernel,exact re-solve launches,-,-,step_total";
+  if (h && h->fused) return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total";
   return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
 }
 

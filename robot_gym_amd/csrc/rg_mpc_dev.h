@@ -68,6 +68,7 @@ struct DevState {
   int *warm_key;        // [B] contact mask the stored iterate belongs to (-1 = none)
   int *bins;            // [10][B]: [0..4] robots per stance count, [5..9] retry lists for the active-set pass
   int *counts;          // [16]: [0..4] robots per stance count, [7] failures, [8..12] retry-list lengths
+  int *counts_next;     // [16] the other half of the double-buffered counters: zeroed by the front kernel for the next tick (no memset node)
   int *iters;           // [B] solver iterations of the last tick (ADMM, plus the exact re-solve's if it ran)
 };
 
