@@ -25,6 +25,7 @@ import torch
 
 BATCH_PER_GPU = 4096
 HORIZON = 10
+EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the timed region
 # algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off)
 ALGO_BYTES_PER_STEP = 1110
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -173,6 +174,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_kernel_events:
+        # per-kernel HIP events on every 4th step of the timed region (an event record costs ~4-5 us of stream time)
+        ctl._handle.profile_stride(EVENT_STRIDE)
         ctl._handle.profile_begin(args.steps)
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -73,7 +73,8 @@ struct rg_mpc_handle {
   std::string err;
   // optional per-kernel event timing
   std::vector<hipEvent_t> ev;   // RG_PROF_EV events per profiled step
-  int prof_max = 0, prof_n = 0;
+  int prof_max = 0, prof_n = 0, prof_stride = 1;   // events are recorded on every prof_stride-th step
+  long long tick = 0;
   bool force_lds_kernel = false;
   int qp_variant = 0;
   bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
@@ -318,7 +319,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
   { int *t_ = h->st.counts; h->st.counts = h->st.counts_next; h->st.counts_next = t_; }   // this tick's counters were zeroed by the previous tick's front kernel
-  hipEvent_t *pev = (h->prof_n < h->prof_max) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
+  hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);   // one wave per workgroup: 16 k lanes spread over all CUs
   HIPCHK(h, hipGetLastError());
@@ -328,15 +329,11 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // on MI355X this is ~8 % slower than back-to-back launches, so it is off by default.
   if (h->fused) {
     // horizon 10, ADMM: one launch over all stance-leg counts, then the (normally empty) exact re-solves
-    if (pev) HIPCHK(h, hipEventRecord(pev[2], s));
+    // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
     HIPCHK(h, launch_qp_fused_h10(h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
-    if (pev) { HIPCHK(h, hipEventRecord(pev[3], s)); HIPCHK(h, hipEventRecord(pev[4], s)); }
+    if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
     if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
-    if (pev) {
-      HIPCHK(h, hipEventRecord(pev[5], s));
-      for (int k = 6; k <= 10; k++) HIPCHK(h, hipEventRecord(pev[k], s));
-      h->prof_n++;
-    }
+    if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
     return RG_MPC_OK;
   }
   const bool fork = h->concurrent_bins;
@@ -398,13 +395,19 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
     HIPCHK(h, hipEventCreate(&e));
     h->ev.push_back(e);
   }
-  h->prof_max = max_steps; h->prof_n = 0;
+  h->prof_max = max_steps; h->prof_n = 0; h->tick = 0;
   return RG_MPC_OK;
 }
 
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
   if (h && h->fused) return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total";
   return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
+}
+
+int rg_mpc_profile_stride(rg_mpc_handle *h, int32_t stride) {
+  if (!h || stride < 1) { if (h) h->err = "profile_stride: stride must be >= 1"; return RG_MPC_ERR_INVALID; }
+  h->prof_stride = stride;
+  return RG_MPC_OK;
 }
 
 int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void *stream) {
@@ -418,6 +421,12 @@ int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void 
     hipEvent_t *e = &h->ev[(size_t)k * RG_PROF_EV];
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[1])); acc[0] += ms;
+    if (h->fused) {
+      HIPCHK(h, hipEventElapsedTime(&ms, e[1], e[3])); acc[1] += ms;
+      HIPCHK(h, hipEventElapsedTime(&ms, e[3], e[5])); acc[2] += ms;
+      HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[5])); acc[5] += ms;
+      continue;
+    }
     for (int nc = 1; nc <= 4; nc++) { HIPCHK(h, hipEventElapsedTime(&ms, e[2 * nc], e[2 * nc + 1])); acc[nc] += ms; }
     HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[10])); acc[5] += ms;
   }
