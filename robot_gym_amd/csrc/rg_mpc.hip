@@ -80,7 +80,7 @@ struct rg_mpc_handle {
   bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
   bool fused = false;               // H = 10 ADMM: one launch for all stance-leg counts (reserved0 bit5 = per-bin launches, A/B)
   bool grid_per_robot = true;       // fused launch: one workgroup per robot, longest first (reserved0 bit6 = 8 workgroups per CU looping, A/B: 3 % slower)
-  int *counts2 = nullptr;           // [2][16] double-buffered work-list counters
+  int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
   bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -210,6 +210,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   h->grid_per_robot = ((cfg->reserved0 >> 6) & 1) == 0;
   h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
+  h->hcfg.plan = h->fused ? 1 : 0;
   if (rc) { g_create_err = h->err; delete h; return rc; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_err = "no HIP device available"; delete h; return RG_MPC_ERR_NO_DEVICE; }
@@ -229,8 +230,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
   AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N);
   if (cfg->warm_start) { AL(h->st.warm_z, B * RG_WARM_N); AL(h->st.warm_y, B * RG_WARM_N); }
-  AL(h->st.warm_key, B); AL(h->st.bins, 10 * B); AL(h->counts2, 32); AL(h->st.iters, B);
-  h->st.counts = h->counts2; h->st.counts_next = h->counts2 + 16;
+  AL(h->st.warm_key, B); AL(h->st.bins, RG_NLISTS * B); AL(h->counts2, 2 * RG_NCOUNTS); AL(h->st.iters, B); AL(h->st.ncs, B);
+  h->st.counts = h->counts2; h->st.counts_next = h->counts2 + RG_NCOUNTS;
   AL(h->idx_dev, B); AL(h->t0_dev, B);
   CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
   for (int nc = 1; nc <= 4; nc++) {
@@ -404,6 +405,15 @@ const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
   return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
 }
 
+// robots per stance-leg count of the last tick, from the per-robot record (the work lists may be cost classes)
+static int host_bin_counts(rg_mpc_handle *h, int out5[5]) {
+  std::vector<int> nc((size_t)h->B);
+  HIPCHK(h, hipMemcpy(nc.data(), h->st.ncs, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 5; k++) out5[k] = 0;
+  for (int v : nc) if (v >= 0 && v <= 4) out5[v]++;
+  return RG_MPC_OK;
+}
+
 int rg_mpc_profile_stride(rg_mpc_handle *h, int32_t stride) {
   if (!h || stride < 1) { if (h) h->err = "profile_stride: stride must be >= 1"; return RG_MPC_ERR_INVALID; }
   h->prof_stride = stride;
@@ -431,7 +441,7 @@ int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void 
     HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[10])); acc[5] += ms;
   }
   for (int j = 0; j < 6; j++) avg_ms6[j] = n > 0 ? (float)(acc[j] / n) : 0.f;
-  if (robots5) HIPCHK(h, hipMemcpy(robots5, h->st.counts, sizeof(int) * 5, hipMemcpyDeviceToHost));
+  if (robots5) { int tmp[5]; int r_ = host_bin_counts(h, tmp); if (r_) return r_; for (int k = 0; k < 5; k++) robots5[k] = tmp[k]; }
   return n;
 }
 
@@ -468,8 +478,9 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
   if (!h) return RG_MPC_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-  int cnt[16];
+  int cnt[RG_NCOUNTS], per_nc[5];
   HIPCHK(h, hipMemcpy(cnt, h->st.counts, sizeof(cnt), hipMemcpyDeviceToHost));
+  { int r_ = host_bin_counts(h, per_nc); if (r_) return r_; }
   if (iters_sum || iters_max) {   // per-robot iteration counts, reduced here (the kernels keep no global atomics for them)
     std::vector<int> it((size_t)h->B);
     HIPCHK(h, hipMemcpy(it.data(), h->st.iters, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
@@ -478,7 +489,7 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
     if (iters_sum) *iters_sum = sum;
     if (iters_max) *iters_max = mx;
   }
-  if (qp_robots) *qp_robots = cnt[1] + cnt[2] + cnt[3] + cnt[4];
+  if (qp_robots) *qp_robots = per_nc[1] + per_nc[2] + per_nc[3] + per_nc[4];
   if (retried) *retried = cnt[9] + cnt[10] + cnt[11] + cnt[12];
   if (failures) *failures = cnt[7];
   return RG_MPC_OK;
@@ -488,7 +499,9 @@ int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream) {
   if (!h || !out5) return RG_MPC_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-  HIPCHK(h, hipMemcpy(out5, h->st.counts, sizeof(int) * 5, hipMemcpyDeviceToHost));
+  int tmp[5];
+  { int r_ = host_bin_counts(h, tmp); if (r_) return r_; }
+  for (int k = 0; k < 5; k++) out5[k] = tmp[k];
   return RG_MPC_OK;
 }
 

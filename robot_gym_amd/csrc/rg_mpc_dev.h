@@ -9,6 +9,11 @@
 #define RG_MAXH 20
 #define RG_WARM_N 256 // doubles per robot for the stored ADMM iterate (n <= 240)
 #define RG_REC_N 96  // doubles per robot in the front->QP record
+// work lists: [0..4] robots per stance-leg count, [5..9] exact re-solve lists, [10..10+RG_COST_CLASSES) cost
+// classes of the fused launch (entry = robot | stance legs << 24), most expensive class first
+#define RG_COST_CLASSES 8
+#define RG_NLISTS (10 + RG_COST_CLASSES)
+#define RG_NCOUNTS 32 // [0..4] list lengths, [7] failures, [8..12] re-solve list lengths, [16..16+RG_COST_CLASSES) class lengths
 
 // record layout (doubles)
 #define REC_ROLL 0
@@ -48,6 +53,7 @@ struct DevCfg {
   double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count)
   int admm_check, lookahead;
   int solver, warm;
+  int plan, pad1;        // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*)
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };
@@ -66,9 +72,10 @@ struct DevState {
   double *rec;          // [B][RG_REC_N]
   double *warm_z, *warm_y;  // [B][RG_WARM_N] previous-tick ADMM iterate (warm start)
   int *warm_key;        // [B] contact mask the stored iterate belongs to (-1 = none)
-  int *bins;            // [10][B]: [0..4] robots per stance count, [5..9] retry lists for the active-set pass
-  int *counts;          // [16]: [0..4] robots per stance count, [7] failures, [8..12] retry-list lengths
-  int *counts_next;     // [16] the other half of the double-buffered counters: zeroed by the front kernel for the next tick (no memset node)
+  int *bins;            // [RG_NLISTS][B] work lists (see RG_NLISTS)
+  int *counts;          // [RG_NCOUNTS] list lengths and failure count (see RG_NCOUNTS)
+  int *ncs;             // [B] stance-leg count of each robot in the last tick
+  int *counts_next;     // [RG_NCOUNTS] the other half of the double-buffered counters: zeroed by the front kernel for the next tick (no memset node)
   int *iters;           // [B] solver iterations of the last tick (ADMM, plus the exact re-solve's if it ran)
 };
 
