@@ -11,7 +11,7 @@
 #define RG_REC_N 96  // doubles per robot in the front->QP record
 // work lists: [0..4] robots per stance-leg count, [5..9] exact re-solve lists, [10..10+RG_COST_CLASSES) cost
 // classes of the fused launch (entry = robot | stance legs << 24), most expensive class first
-#define RG_COST_CLASSES 8
+#define RG_COST_CLASSES 16
 #define RG_NLISTS (10 + RG_COST_CLASSES)
 #define RG_NCOUNTS 32 // [0..4] list lengths, [7] failures, [8..12] re-solve list lengths, [16..16+RG_COST_CLASSES) class lengths
 
