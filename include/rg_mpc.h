@@ -100,7 +100,7 @@ typedef struct {
   double admm_relax;        /* 1.8 */
   double admm_tol;          /* stop when no z entry moved more than admm_tol * m * g over the last
                                admm_check iterations (1e-6); 0 = fixed iteration count */
-  int32_t admm_check;       /* convergence check period (10) */
+  int32_t admm_check;       /* convergence check period (5) */
   int32_t contact_lookahead;/* EXTENSION (not in upstream, default 0): horizon step k uses the open-loop desired contact
                                state at t + k*dt_plan instead of holding the current contacts */
   int32_t warm_start;       /* opt-in (default 0): start ADMM from the robot's previous-tick (z, y) when its contact set is

@@ -159,7 +159,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
   d->rho = c->admm_rho; d->relax = c->admm_relax;
-  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
+  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
     for (int b = 0; b < H; b++) {

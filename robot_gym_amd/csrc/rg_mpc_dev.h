@@ -50,7 +50,8 @@ struct DevCfg {
   double base_com[3];
   double ik_damping, ik_max_step;
   double rho, relax;
-  double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count)
+  double admm_abs_tol;   // admm_tol * m * g  (0 = fixed count): largest force change over admm_check iterations
+  double admm_prim_tol;  // 10 * admm_abs_tol: largest |x - z| (unprojected vs projected force) accepted at convergence
   int admm_check, lookahead;
   int solver, warm;
   int plan, pad1;        // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*)
