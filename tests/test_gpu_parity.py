@@ -148,3 +148,19 @@ def test_warm_start_stays_within_tolerance(oracle_lib):
     it_warm = np.mean([g["solver_stats"]["iters_mean"] for g in gpu[5:]])
     it_cold = np.mean([g["solver_stats"]["iters_mean"] for g in cold[5:]])
     assert it_warm < 0.8 * it_cold, (it_warm, it_cold)
+
+
+def test_collinear_feet_fall_back_to_force_space(oracle_lib):
+    """Four stance feet on one line: the 6 x 12 wrench map loses rank, the wrench-space body's Cholesky flags
+    it and the robot is re-solved exactly in force space (where alpha keeps P positive definite)."""
+    cfg = MPCConfig.for_robot("ghost")
+    state, cmd, t_off = synthetic.make_states(64, cfg, seed=21, phase_offsets=False)   # t = 0: all four legs in stance
+    fp = state["foot_pos"].reshape(4, 3, -1).copy()
+    fp[:, 1, ::2] = 0.0            # every other robot: all feet on the body's x axis
+    fp[:, 2, ::2] = fp[0, 2, ::2]  # ... at one height
+    state["foot_pos"] = fp.reshape(12, -1).astype(np.float32)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=2)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=2)
+    _check(gpu, orc)
+    assert gpu[0]["bins"][4] == 64
+    assert gpu[0]["solver_stats"]["retried_exact"] >= 32 and gpu[0]["solver_stats"]["failures"] == 0
