@@ -196,16 +196,18 @@ def main():
     # robot state on the host -- pinned buffers, one upload of all inputs and one download of the action slab per tick.
     pcie_value = None
     if world == 1:
+        from robot_gym_amd.controllers.mpc.batched import PackedState
         names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
-        host = {n: dev[n].cpu().pin_memory() for n in names_io}
+        ps = PackedState(B, device)     # what MPCVecEnv uses: one pinned slab -> one H2D copy per tick
+        for n in names_io:
+            ps.host[n].copy_(dev[n].cpu())
         act_host = torch.empty(B, 60, dtype=torch.float32).pin_memory()
         nio = max(5, min(args.steps, 20))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for k in range(nio):
-            for n in names_io:
-                dev[n].copy_(host[n], non_blocking=True)
-            act_host.copy_(ctl.get_action(0.01 * (args.warmup + args.steps + k), dev), non_blocking=True)
+            sdev = ps.upload()
+            act_host.copy_(ctl.get_action(0.01 * (args.warmup + args.steps + k), sdev), non_blocking=True)
         torch.cuda.synchronize()
         pcie_value = B * nio / (time.perf_counter() - t1)
 

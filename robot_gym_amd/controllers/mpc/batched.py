@@ -17,6 +17,29 @@ STATE_FIELDS = (("rpy", 3, torch.float32), ("rpy_rate", 3, torch.float32), ("v_w
                 ("jac", 36, torch.float32), ("contact", 4, torch.int32))
 
 
+class PackedState:
+    """Host-resident robot state staged for ONE upload per tick: every STATE_FIELDS array is a view into a single
+    pinned [77, B] 32-bit host slab and a matching device slab (rows in STATE_FIELDS order; `contact` is the
+    int32 view of its rows), so the gym side pays one H2D copy instead of eight."""
+
+    def __init__(self, batch, device, pin=None):
+        words = sum(c for _, c, _ in STATE_FIELDS)
+        pin = torch.cuda.is_available() if pin is None else pin
+        self.host_slab = torch.zeros(words, batch, dtype=torch.float32, pin_memory=pin)
+        self.dev_slab = torch.zeros(words, batch, dtype=torch.float32, device=device)
+        self.host, self.dev = {}, {}
+        row = 0
+        for name, comps, dt in STATE_FIELDS:
+            h, d = self.host_slab[row:row + comps], self.dev_slab[row:row + comps]
+            self.host[name] = h if dt == torch.float32 else h.view(dt)
+            self.dev[name] = d if dt == torch.float32 else d.view(dt)
+            row += comps
+
+    def upload(self):
+        self.dev_slab.copy_(self.host_slab, non_blocking=True)
+        return self.dev
+
+
 def command_with_offsets(params, offsets, batch):
     """(vx, wz) or (vx, vy, wz) per robot -> component-major [3,B] command with the robot's
     offsets added: lin = [vx + VX_OFFSET, vy + VY_OFFSET, 0], ang = wz + WZ_OFFSET

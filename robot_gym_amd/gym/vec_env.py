@@ -10,7 +10,7 @@ rg_mpc_step for all envs, downloads the [B,60] action slab once and scatters it.
 import numpy as np
 import torch
 
-from robot_gym_amd.controllers.mpc.batched import BatchedMPCController, STATE_FIELDS
+from robot_gym_amd.controllers.mpc.batched import BatchedMPCController, PackedState
 from robot_gym_amd.controllers.mpc.mpc_controller import config_from_robot
 
 
@@ -28,8 +28,8 @@ class MPCVecEnv:
         self._dev = self.controller.device
         self._jacobian_fn = jacobian_fn or (lambda env, leg: env.simulation.controller.kinematics_model.leg_jacobian(leg))
         pin = torch.cuda.is_available()
-        self._host = {n: torch.zeros(c, B, dtype=dt, pin_memory=pin) for n, c, dt in STATE_FIELDS}
-        self._devbuf = {n: torch.zeros(c, B, dtype=dt, device=self._dev) for n, c, dt in STATE_FIELDS}
+        self._state = PackedState(B, self._dev, pin)   # one pinned slab, one device slab, one copy per tick
+        self._host, self._devbuf = self._state.host, self._state.dev
         self._act_host = torch.zeros(B, 60, dtype=torch.float32, pin_memory=pin)
         self._t = np.zeros(B)
 
@@ -52,8 +52,7 @@ class MPCVecEnv:
             h["contact"][:, b] = np.asarray(rb.GetFootContacts(), dtype=np.int32)
             h["jac"][:, b] = np.stack([self._jacobian_fn(env, leg) for leg in range(4)]).reshape(36)
             self._t[b] = env.simulation.GetTimeSinceReset()
-        for n in self._host:
-            self._devbuf[n].copy_(self._host[n], non_blocking=True)
+        self._state.upload()
 
     def step(self, actions):
         """actions: [B,2] or [B,3] velocity commands.  Returns stacked (obs, reward, done, info)."""
