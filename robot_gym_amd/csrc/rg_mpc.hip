@@ -457,8 +457,8 @@ int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   const int bytes = 160 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) { HIPCHK(h, hipFuncSetAttribute((const void *)rg_debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)); attr_set = true; }
+  static bool attr_done[64] = {};
+  if (lds_attr_needed(attr_done)) HIPCHK(h, hipFuncSetAttribute((const void *)rg_debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   rg_debug_poison_lds_kernel<<<dim3(h->cu_count * 4), dim3(256), bytes, (hipStream_t)stream>>>(bytes / 8);
   HIPCHK(h, hipGetLastError());
   return RG_MPC_OK;
