@@ -58,6 +58,29 @@ def traffic_from_profile(kernel_name, batch):
     return None
 
 
+def issue_view_from_profile(kernel_name, batch):
+    """Secondary (non-HBM) view of the dominant kernel from the committed rocprofv3 SQ counter passes of this same
+    command: fraction of SIMD issue cycles with a VALU instruction, LDS pipe busy fraction, occupied wave slots.
+    MI355X: 8 XCDs x 32 CUs x 4 SIMDs; SQ_* cycle counters are in quad-cycles, GRBM_GUI_ACTIVE sums the 8 XCDs."""
+    try:
+        import csv
+        meta = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+        if int(meta.get("batch", -1)) != int(batch):
+            return None
+        base = kernel_name.split("<")[0]
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_pmc_per_launch.csv"))):
+            if base in r["kernel"] and "true>" not in r["kernel"]:
+                cyc = float(r["GRBM_GUI_ACTIVE"]) / 8.0
+                return {"valu_busy_frac": round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / (cyc * 1024), 3),
+                        "lds_busy_frac": round(4.0 * float(r["SQ_ACTIVE_INST_LDS"]) / (cyc * 256), 3),
+                        "wave_slot_occupancy": round(4.0 * float(r["SQ_WAVE_CYCLES"]) / (cyc * 2048), 3),
+                        "valu_instructions_per_unit": round(float(r["SQ_INSTS_VALU"]) / float(r["SQ_WAVES"])),
+                        "source": "profiles/r1_pmc_per_launch.csv (2 waves/SIMD by register budget = 2048 wave slots)"}
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, budget_s=10.0):
     """Time the oracle (port) on the host cores on a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -236,9 +259,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(names[dom], B),
                          "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,
                          "avg_launch_ms": kms[dom],
+                         "issue_view": issue_view_from_profile(names[dom], B),
                          "kernel_ms": {n: round(x, 4) for n, x in zip(names + ["step_total"], kms) if n != "-"},
                          "robots_per_stance_count": robots,
-                         "note": "path is LDS/latency-bound, not HBM-bound (SURVEY.md 7.3-2); see DESIGN.md section 5 for the FLOP/LDS view"},
+                         "note": "path is instruction-issue/latency-bound, not HBM-bound (SURVEY.md 7.3-2): see issue_view and DESIGN.md section 5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -251,13 +251,16 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   *out = h;
   int r = rg_mpc_reset(h, nullptr, batch, 0.0, nullptr);
   if (r) { g_create_err = h->err; rg_mpc_destroy(h); *out = nullptr; return r; }
-  hipDeviceSynchronize();
+  {
+    hipError_t e_ = hipDeviceSynchronize();   // the reset kernel has run: create() reports device faults itself
+    if (e_ != hipSuccess) { g_create_err = std::string("create: ") + hipGetErrorString(e_); rg_mpc_destroy(h); *out = nullptr; return RG_MPC_ERR_HIP; }
+  }
   return RG_MPC_OK;
 }
 
 void rg_mpc_destroy(rg_mpc_handle *h) {
   if (!h) return;
-  hipSetDevice(h->device);
+  (void)hipSetDevice(h->device);
   for (void *p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_front) (void)hipEventDestroy(h->ev_front);
