@@ -29,6 +29,7 @@ EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the
 # algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off)
 ALGO_BYTES_PER_STEP = 1110
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+F64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (v_fma_f64 issues at 4 cycles per wave)
 
 
 def make_device_state(cfg, B, seed, device):
@@ -71,7 +72,11 @@ def issue_view_from_profile(kernel_name, batch):
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_pmc_per_launch.csv"))):
             if base in r["kernel"] and "true>" not in r["kernel"]:
                 cyc = float(r["GRBM_GUI_ACTIVE"]) / 8.0
-                return {"valu_busy_frac": round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / (cyc * 1024), 3),
+                flops = None
+                if r.get("SQ_INSTS_VALU_FMA_F64") not in (None, "", "nan"):   # wave-level instruction counts x 64 lanes
+                    flops = 64.0 * (2.0 * float(r["SQ_INSTS_VALU_FMA_F64"]) + float(r["SQ_INSTS_VALU_ADD_F64"]) + float(r["SQ_INSTS_VALU_MUL_F64"]))
+                return {"f64_flop_per_launch": flops, "f64_vector_peak_tflops": F64_VECTOR_PEAK_TFLOPS,
+                        "valu_busy_frac": round(4.0 * float(r["SQ_ACTIVE_INST_VALU"]) / (cyc * 1024), 3),
                         "lds_busy_frac": round(4.0 * float(r["SQ_ACTIVE_INST_LDS"]) / (cyc * 256), 3),
                         "wave_slot_occupancy": round(4.0 * float(r["SQ_WAVE_CYCLES"]) / (cyc * 2048), 3),
                         "valu_instructions_per_unit": round(float(r["SQ_INSTS_VALU"]) / float(r["SQ_WAVES"])),
@@ -79,6 +84,14 @@ def issue_view_from_profile(kernel_name, batch):
     except Exception:
         pass
     return None
+
+
+def with_f64_rate(view, dur_s):
+    """f64 vector FLOP/s of the dominant launch: counted FLOPs (committed counter pass) / its live hipEvent duration."""
+    if view and view.get("f64_flop_per_launch") and dur_s > 0:
+        view["f64_tflops_achieved"] = round(view["f64_flop_per_launch"] / dur_s / 1e12, 2)
+        view["f64_frac_of_vector_peak"] = round(view["f64_tflops_achieved"] / view["f64_vector_peak_tflops"], 3)
+    return view
 
 
 def cpu_baseline(cfg, budget_s=10.0):
@@ -259,7 +272,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(names[dom], B),
                          "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,
                          "avg_launch_ms": kms[dom],
-                         "issue_view": issue_view_from_profile(names[dom], B),
+                         "issue_view": with_f64_rate(issue_view_from_profile(names[dom], B), dur_s),
                          "kernel_ms": {n: round(x, 4) for n, x in zip(names + ["step_total"], kms) if n != "-"},
                          "robots_per_stance_count": robots,
                          "note": "path is instruction-issue/latency-bound, not HBM-bound (SURVEY.md 7.3-2): see issue_view and DESIGN.md section 5"},

@@ -27,7 +27,7 @@ stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_flops"):
     for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
