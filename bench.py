@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--relax", type=float, default=None)
     ap.add_argument("--tol", type=float, default=None)
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region (roofline.kernel_ms is then empty)")
+    ap.add_argument("--horizon", type=int, default=HORIZON, help="MPC horizon (10 = the headline workload; 20 = BASELINE configs[4] shape)")
+    ap.add_argument("--lookahead", action="store_true", help="opt-in contact look-ahead extension (per-step contact schedule from the open-loop gait)")
     ap.add_argument("--reserved0", type=int, default=0, help="tuning bits passed to rg_mpc_config.reserved0")
     args = ap.parse_args()
 
@@ -189,7 +191,9 @@ def main():
         over["admm_relax"] = args.relax
     if args.tol is not None:
         over["admm_tol"] = args.tol
-    cfg = MPCConfig.for_robot("ghost", horizon=HORIZON, **over)
+    if args.lookahead:
+        over["contact_lookahead"] = 1
+    cfg = MPCConfig.for_robot("ghost", horizon=args.horizon, **over)
     B = args.batch
     # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard
     state, cmd, t_off, contact, dev = make_device_state(cfg, B, seed=rank, device=device)
@@ -260,11 +264,11 @@ def main():
         dur_s = kms[dom] * 1e-3
         achieved = (ALGO_BYTES_PER_STEP * units[dom] / dur_s) / 1e9 if dur_s > 0 else 0.0
         out = {
-            "metric": "MPC controller steps/sec (whole node), batch=4096 quadrupeds, horizon=10",
+            "metric": f"MPC controller steps/sec (whole node), batch={B} quadrupeds, horizon={args.horizon}",
             "value": value, "unit": "controller steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch={B} quadrupeds per GPU, horizon={HORIZON}, randomised (vx,vy,wz) commands (BASELINE configs[2])",
+            "config": {"workload": f"batch={B} quadrupeds per GPU, horizon={args.horizon}{' with contact look-ahead' if args.lookahead else ''}, randomised (vx,vy,wz) commands (BASELINE configs[2])",
                        "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}", "admm_iterations": stats,
                        "warm_start": bool(cfg.warm_start), "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
                        "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective"},

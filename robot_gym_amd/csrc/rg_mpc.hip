@@ -493,8 +493,11 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
     if (iters_max) *iters_max = mx;
   }
   if (qp_robots) *qp_robots = per_nc[1] + per_nc[2] + per_nc[3] + per_nc[4];
-  if (retried) *retried = cnt[9] + cnt[10] + cnt[11] + cnt[12];
-  if (failures) *failures = cnt[7];
+  // robots the ADMM pass left unconverged: re-solved exactly where the plan has a re-solve pass, failures otherwise
+  const int unconverged = cnt[9] + cnt[10] + cnt[11] + cnt[12];
+  const bool resolved = h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry;
+  if (retried) *retried = resolved ? unconverged : 0;
+  if (failures) *failures = cnt[7] + (resolved ? 0 : unconverged);
   return RG_MPC_OK;
 }
 
