@@ -166,6 +166,10 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
  * step (HOST out[5]); synchronises the stream. */
 int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream);
 
+/* Per-robot view of the last step (HOST arrays of length batch, either may be NULL; synchronises the stream):
+ * solver iterations and the number of stance legs the robot's QP was solved for. */
+int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_legs_B, void *stream);
+
 /* Solver statistics of the last step (synchronises the stream): sum and max of solver iterations
  * (ADMM iterations / active-set constraint additions) over the robots that had a QP, the number of
  * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO) and how many solves failed

@@ -47,7 +47,7 @@ class COutPtrs(C.Structure):
 
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
-           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -84,6 +84,8 @@ def load_library(path=None):
     L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
     L.rg_mpc_profile_end.restype = i32
     L.rg_mpc_kernel_names.restype = C.c_char_p
+    L.rg_mpc_last_iterations.argtypes = [fp, C.POINTER(i32), C.POINTER(i32), fp]
+    L.rg_mpc_last_iterations.restype = i32
     L.rg_mpc_profile_stride.argtypes = [fp, i32]
     L.rg_mpc_profile_stride.restype = i32
     L.rg_mpc_debug_poison_lds.argtypes = [fp, fp]
@@ -178,6 +180,14 @@ class MpcHandle:
 
     def profile_begin(self, max_steps):
         self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))
+
+    def last_iterations(self, batch, stream=None):
+        """(iterations[B], stance_legs[B]) of the last step as numpy int32 arrays."""
+        import numpy as np
+        it = np.zeros(batch, dtype=np.int32)
+        nc = np.zeros(batch, dtype=np.int32)
+        self._check(self._lib.rg_mpc_last_iterations(self._h, it.ctypes.data_as(C.POINTER(i32)), nc.ctypes.data_as(C.POINTER(i32)), stream))
+        return it, nc
 
     def profile_stride(self, stride):
         self._check(self._lib.rg_mpc_profile_stride(self._h, int(stride)))

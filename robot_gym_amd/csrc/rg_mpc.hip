@@ -501,6 +501,15 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
   return RG_MPC_OK;
 }
 
+int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_legs_B, void *stream) {
+  if (!h || (!iters_B && !stance_legs_B)) return RG_MPC_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  if (iters_B) HIPCHK(h, hipMemcpy(iters_B, h->st.iters, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
+  if (stance_legs_B) HIPCHK(h, hipMemcpy(stance_legs_B, h->st.ncs, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
+  return RG_MPC_OK;
+}
+
 int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream) {
   if (!h || !out5) return RG_MPC_ERR_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
