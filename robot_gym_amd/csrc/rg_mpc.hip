@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "rg_front_kernel.inc"
+#include "rg_qp_common.inc"
 #include "rg_qp_lds_kernel.inc"
 #include "rg_qp_row_kernel.inc"
 #include "rg_qp_tile_kernel.inc"
