@@ -258,3 +258,34 @@ def test_step_argument_validation_reports_errors():
     act = ctl.get_action(0.0, dev)                                                  # still usable afterwards
     assert torch.isfinite(act).all()
     ctl.close()
+
+
+def test_introspection_views_agree():
+    """Per-robot iteration view, solver statistics, bin counts and the packed host staging slab describe the same step."""
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController, PackedState
+    cfg = MPCConfig.for_robot("ghost")
+    B = 257
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=5)
+    contact = synthetic.gait_consistent_contacts(cfg, t_off + 0.03, state["_flip"])
+    ctl = BatchedMPCController(B, cfg)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    ps = PackedState(B, ctl.device)
+    for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac"):
+        ps.host[n].copy_(torch.from_numpy(np.ascontiguousarray(state[n])))
+    ps.host["contact"].copy_(torch.from_numpy(contact))
+    act_packed = ctl.get_action(0.03, ps.upload()).cpu().numpy().copy()
+    it, nc = ctl._handle.last_iterations(B, ctl._stream())
+    stats, bins = ctl.solver_stats(), ctl.bin_counts()
+    assert int(it.sum()) == stats["iters_sum"] and int(it.max()) == stats["iters_max"]
+    assert [int((nc == k).sum()) for k in range(5)] == list(bins)
+    assert stats["qp_robots"] == int((nc > 0).sum()) and np.all(it[nc == 0] == 0) and np.all(it[nc > 0] > 0)
+    assert ctl._handle.profile_window_names()[1] == "rg_qp_fused_kernel"
+    # same step from separately allocated device tensors (fresh controller): identical actions
+    ctl2 = BatchedMPCController(B, cfg)
+    ctl2.reset_at(-t_off)
+    ctl2.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    dev = {n: torch.from_numpy(np.ascontiguousarray(state[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+    dev["contact"] = torch.from_numpy(contact).cuda()
+    assert np.array_equal(ctl2.get_action(0.03, dev).cpu().numpy(), act_packed)
+    ctl.close(); ctl2.close()
