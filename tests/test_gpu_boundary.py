@@ -289,3 +289,23 @@ def test_introspection_views_agree():
     dev["contact"] = torch.from_numpy(contact).cuda()
     assert np.array_equal(ctl2.get_action(0.03, dev).cpu().numpy(), act_packed)
     ctl.close(); ctl2.close()
+
+
+def test_non_finite_state_is_counted_and_contained(oracle_lib):
+    """Robots whose state holds a NaN / Inf are reported in `failures` (their command is meaningless: the cone
+    projection's fmin/fmax turn NaNs into finite numbers); every other robot of the batch still matches the oracle."""
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    cfg = MPCConfig.for_robot("ghost")
+    B = 96
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=17)
+    bad = [5, 40]
+    state["rpy"][0, bad[0]] = np.nan
+    state["foot_pos"][2, bad[1]] = np.inf
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=2)
+    assert gpu[-1]["solver_stats"]["failures"] == len(bad)
+    good = np.array([b for b in range(B) if b not in bad])
+    clean = {k: (v[:, good] if hasattr(v, "shape") and v.ndim == 2 else v) for k, v in state.items()}
+    orc = helpers.run_oracle(oracle_lib, cfg, clean, cmd[:, good], t_off[good], ticks=2)
+    for g, o in zip(gpu, orc):
+        m = helpers.compare_tick({"action": g["action"][good]}, o)
+        assert m["tau_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, m
