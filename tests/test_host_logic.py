@@ -58,3 +58,23 @@ def test_synthetic_states_are_deterministic_and_shaped():
     assert set(np.unique(c.sum(0))) <= {2, 4}  # trot: a diagonal pair or all four
     fixed, cf, _ = synthetic.make_states(16, cfg, seed=0, fixed_cmd=(0.3, 0.0, 0.0))
     assert np.all(cf[0] == np.float32(0.3)) and np.all(cf[1:] == 0)
+
+
+def test_packed_state_views_share_one_slab():
+    """PackedState: every field is a contiguous view into ONE [77, B] slab (host and device side), contact as int32."""
+    import torch
+    from robot_gym_amd.controllers.mpc.batched import PackedState, STATE_FIELDS
+    B = 5
+    ps = PackedState(B, torch.device("cpu"), pin=False)
+    assert ps.host_slab.shape == (sum(c for _, c, _ in STATE_FIELDS), B) == (77, B)
+    row = 0
+    for name, comps, dt in STATE_FIELDS:
+        h = ps.host[name]
+        assert h.shape == (comps, B) and h.dtype == dt and h.is_contiguous()
+        assert h.data_ptr() == ps.host_slab[row].data_ptr()
+        row += comps
+    ps.host["contact"][:] = torch.arange(4 * B, dtype=torch.int32).reshape(4, B)
+    ps.host["rpy"][:] = 1.5
+    dev = ps.upload()
+    assert torch.equal(dev["contact"], ps.host["contact"]) and torch.equal(dev["rpy"], ps.host["rpy"])
+    assert dev["jac"].data_ptr() == ps.dev_slab[37].data_ptr()
