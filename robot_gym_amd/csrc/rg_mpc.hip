@@ -79,7 +79,7 @@ struct rg_mpc_handle {
   bool force_lds_kernel = false;
   int qp_variant = 0;
   bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
-  bool fused = false;               // H = 10 ADMM: one launch for all stance-leg counts (reserved0 bit5 = per-bin launches, A/B)
+  bool fused = false;               // H = 10 / 20, ADMM: one launch for all stance-leg counts (reserved0 bit5 = per-count launches, A/B)
   bool grid_per_robot = true;       // fused launch: one workgroup per robot, longest first (reserved0 bit6 = 8 workgroups per CU looping, A/B: 3 % slower)
   int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
@@ -207,7 +207,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && cfg->horizon == 10 && !cfg->contact_lookahead;
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
   h->wrench_space = ((cfg->reserved0 >> 4) & 1) == 0;
-  h->fused = h->wrench_space && ((cfg->reserved0 >> 5) & 1) == 0 && (cfg->reserved0 & 15) == 0 && cfg->horizon == 10 && cfg->solver != RG_SOLVER_ACTIVE_SET;
+  h->fused = h->wrench_space && ((cfg->reserved0 >> 5) & 1) == 0 && (cfg->reserved0 & 15) == 0 && (cfg->horizon == 10 || cfg->horizon == 20) && cfg->solver != RG_SOLVER_ACTIVE_SET;
   h->grid_per_robot = ((cfg->reserved0 >> 6) & 1) == 0;
   h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
@@ -333,9 +333,9 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // launches are forked onto internal streams and joined back into the caller's stream.  Measured
   // on MI355X this is ~8 % slower than back-to-back launches, so it is off by default.
   if (h->fused) {
-    // horizon 10, ADMM: one launch over all stance-leg counts, then the (normally empty) exact re-solves
+    // horizon 10 / 20, ADMM: one launch over all stance-leg counts, then (horizon 10) the normally empty exact re-solves
     // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
-    HIPCHK(h, launch_qp_fused_h10(h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
+    HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
     if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
