@@ -83,6 +83,7 @@ struct rg_mpc_handle {
   bool grid_per_robot = true;       // fused launch: one workgroup per robot, longest first (reserved0 bit6 = 8 workgroups per CU looping, A/B: 3 % slower)
   int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
+  int retry_max_nc = 0;             // ... for robots with up to this many stance legs (4 at horizon 10, 2 at horizon 20)
   bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
   hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_front = nullptr, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -204,7 +205,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
   h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
-  h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && cfg->horizon == 10 && !cfg->contact_lookahead;
+  h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && (cfg->horizon == 10 || cfg->horizon == 20) && !cfg->contact_lookahead;
+  h->retry_max_nc = !h->auto_retry ? 0 : (cfg->horizon == 10 ? 4 : 2);
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
   h->wrench_space = ((cfg->reserved0 >> 4) & 1) == 0;
   h->fused = h->wrench_space && ((cfg->reserved0 >> 5) & 1) == 0 && (cfg->reserved0 & 15) == 0 && (cfg->horizon == 10 || cfg->horizon == 20) && cfg->solver != RG_SOLVER_ACTIVE_SET;
@@ -337,7 +339,14 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
     HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
-    if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
+    if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
+    else if (h->auto_retry) {
+      for (int nc = h->retry_max_nc; nc >= 1; nc--) {
+        hipError_t lerr;
+        launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2);
+        HIPCHK(h, lerr);
+      }
+    }
     if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
     return RG_MPC_OK;
   }
@@ -358,7 +367,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
           launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, exact ? 1 : 0)) {
         HIPCHK(h, lerr);
         launched = true;
-        if (h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry) {   // exact re-solve of the robots ADMM left unconverged
+        if (h->auto_retry && nc <= h->retry_max_nc) {   // exact re-solve of the robots ADMM left unconverged
           launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, 2);
           HIPCHK(h, lerr);
         }
@@ -495,10 +504,10 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
   }
   if (qp_robots) *qp_robots = per_nc[1] + per_nc[2] + per_nc[3] + per_nc[4];
   // robots the ADMM pass left unconverged: re-solved exactly where the plan has a re-solve pass, failures otherwise
-  const int unconverged = cnt[9] + cnt[10] + cnt[11] + cnt[12];
-  const bool resolved = h->cfg.solver == RG_SOLVER_AUTO && h->auto_retry;
-  if (retried) *retried = resolved ? unconverged : 0;
-  if (failures) *failures = cnt[7] + (resolved ? 0 : unconverged);
+  int resolved = 0, unresolved = 0;
+  for (int nc = 1; nc <= 4; nc++) (nc <= h->retry_max_nc ? resolved : unresolved) += cnt[8 + nc];
+  if (retried) *retried = resolved;
+  if (failures) *failures = cnt[7] + unresolved;
   return RG_MPC_OK;
 }
 

@@ -164,3 +164,18 @@ def test_collinear_feet_fall_back_to_force_space(oracle_lib):
     _check(gpu, orc)
     assert gpu[0]["bins"][4] == 64
     assert gpu[0]["solver_stats"]["retried_exact"] >= 32 and gpu[0]["solver_stats"]["failures"] == 0
+
+
+@pytest.mark.parametrize("gait", ["pace", "bound"])
+def test_unbalanced_gaits_horizon_20(oracle_lib, gait):
+    """Horizon 20: robots with one or two stance legs that ADMM cannot converge are re-solved exactly too
+    (n <= 120 fits the active-set kernel's LDS); three and four legs have no exact pass at this horizon."""
+    phases = {"pace": (0.0, 0.5, 0.0, 0.5), "bound": (0.0, 0.0, 0.5, 0.5)}[gait]
+    cfg = MPCConfig.for_robot("ghost", horizon=20, duty_factor=(0.5,) * 4, init_phase=phases, init_state=(1, 1, 1, 1))
+    state, cmd, t_off = synthetic.make_states(48, cfg, seed=23)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=3, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=3, jitter=0.1)
+    _check(gpu, orc)
+    stats = gpu[-1]["solver_stats"]
+    assert stats["failures"] == 0 and stats["retried_exact"] > 0
+    assert gpu[-1]["bins"][3] == 0 and gpu[-1]["bins"][4] == 0   # duty 0.5: never more than two stance legs
