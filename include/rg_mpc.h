@@ -174,8 +174,8 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
  * (ADMM iterations / active-set constraint additions) over the robots that had a QP, the number of
  * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO) and how many solves failed
  * (robots with a non-finite input or command, active-set breakdowns, plus robots ADMM left unconverged
- * where the plan has no exact re-solve pass: three and four stance legs at horizon 20, contact look-ahead,
- * RG_SOLVER_ADMM). */
+ * where the plan has no exact re-solve pass: three and four stance legs at horizon 20 (incl. look-ahead
+ * at horizon 20), RG_SOLVER_ADMM). */
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);
 

@@ -120,7 +120,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
-  if (c->solver == RG_SOLVER_ACTIVE_SET && ((c->reserved0 & 7) != 0 || c->horizon != 10 || c->contact_lookahead)) { err = "the active-set solver needs the tiled QP kernel, horizon 10 and no contact look-ahead"; return RG_MPC_ERR_INVALID; }
+  if (c->solver == RG_SOLVER_ACTIVE_SET && ((c->reserved0 & 7) != 0 || c->horizon != 10)) { err = "the active-set solver needs the tiled QP kernel and horizon 10"; return RG_MPC_ERR_INVALID; }
   if (c->contact_lookahead && ((c->reserved0 & 7) != 0 || (c->horizon != 10 && c->horizon != 20))) { err = "contact_lookahead needs the tiled QP kernel (reserved0 bits 0-2 clear) and horizon 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 12; i++) if (!(c->motor_dir[i] == 1.0 || c->motor_dir[i] == -1.0)) { err = "motor_dir must be +-1"; return RG_MPC_ERR_INVALID; }
@@ -205,7 +205,9 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
   h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
-  h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && (cfg->horizon == 10 || cfg->horizon == 20) && !cfg->contact_lookahead;
+  // exact re-solve pass: every stance-leg count at horizon 10 (also under contact look-ahead, where every robot
+  // solves the four-leg problem), one and two legs at horizon 20 (n <= 120)
+  h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && (cfg->horizon == 10 || (cfg->horizon == 20 && !cfg->contact_lookahead));
   h->retry_max_nc = !h->auto_retry ? 0 : (cfg->horizon == 10 ? 4 : 2);
   h->qp_variant = (cfg->reserved0 >> 1) & 3;
   h->wrench_space = ((cfg->reserved0 >> 4) & 1) == 0;

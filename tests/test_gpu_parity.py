@@ -179,3 +179,19 @@ def test_unbalanced_gaits_horizon_20(oracle_lib, gait):
     stats = gpu[-1]["solver_stats"]
     assert stats["failures"] == 0 and stats["retried_exact"] > 0
     assert gpu[-1]["bins"][3] == 0 and gpu[-1]["bins"][4] == 0   # duty 0.5: never more than two stance legs
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_contact_lookahead_exact_solver(oracle_lib, solver):
+    """Contact look-ahead at horizon 10 with the exact solver (alone, and as the re-solve pass behind a deliberately
+    short ADMM cap): blocks of legs not in contact at a step are taken out of the problem, not projected."""
+    over = dict(solver=solver) if solver == 1 else dict(solver=2, admm_iters=40)
+    cfg = MPCConfig.for_robot("ghost", contact_lookahead=1, **over)
+    state, cmd, t_off = synthetic.make_states(64, cfg, seed=29)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    _check(gpu, orc)
+    stats = gpu[-1]["solver_stats"]
+    assert stats["failures"] == 0
+    if solver == 2:
+        assert stats["retried_exact"] > 0
