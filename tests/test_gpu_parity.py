@@ -195,3 +195,17 @@ def test_contact_lookahead_exact_solver(oracle_lib, solver):
     assert stats["failures"] == 0
     if solver == 2:
         assert stats["retried_exact"] > 0
+
+
+def test_steady_state_filter_full_batch_1024(oracle_lib):
+    """24 ticks at batch 1024: the 20-tick velocity window is full, so the QPs see the whole velocity error
+    (about ten active constraints per trot QP instead of one or two while the window fills), the cost-class
+    launch order has history to work with, and both QP bodies run in the regime the bench measures."""
+    cfg = MPCConfig.for_robot("ghost")
+    state, cmd, t_off = synthetic.make_states(1024, cfg, seed=31)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=24, jitter=0.02)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=24, jitter=0.02)
+    _check(gpu, orc)
+    last = gpu[-1]
+    assert last["solver_stats"]["failures"] == 0 and last["bins"][2] > 0 and last["bins"][4] > 0
+    assert last["solver_stats"]["iters_mean"] > 40   # steady-state QPs are the hard ones
