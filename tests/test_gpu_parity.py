@@ -209,3 +209,17 @@ def test_steady_state_filter_full_batch_1024(oracle_lib):
     last = gpu[-1]
     assert last["solver_stats"]["failures"] == 0 and last["bins"][2] > 0 and last["bins"][4] > 0
     assert last["solver_stats"]["iters_mean"] > 40   # steady-state QPs are the hard ones
+
+
+def test_gait_phase_bit_exact_after_an_hour(oracle_lib):
+    """Gait phase and leg states stay bit-exact when the controller clock is large (robots reset up to an hour
+    ago): the phase is fmod(t + phase0 * T, T) / T in float64 with no FMA contraction on either side."""
+    cfg = MPCConfig.for_robot("ghost")
+    state, cmd, _ = synthetic.make_states(128, cfg, seed=37)
+    t_off = np.random.default_rng(37).uniform(0.0, 3600.0, 128)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=12, jitter=0.05)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=12, jitter=0.05)
+    _check(gpu, orc)
+    for g, o in zip(gpu, orc):
+        assert np.array_equal(g["phase"], o["phase"].astype(np.float32))
+        assert np.array_equal(g["leg_state"], o["leg_state"]) and np.array_equal(g["desired_state"], o["desired"])
