@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RG_MPC_ABI_VERSION 1
+#define RG_MPC_ABI_VERSION 2
 #define RG_MPC_MAX_HORIZON 20
 #define RG_MPC_NUM_LEGS 4
 #define RG_MPC_NUM_MOTORS 12
@@ -46,8 +46,8 @@ typedef enum {
  * model/robots/ghost/ctrl_constants.py:32-37 */
 enum { RG_LEG_SWING = 0, RG_LEG_STANCE = 1, RG_LEG_EARLY_CONTACT = 2, RG_LEG_LOSE_CONTACT = 3 };
 
-/* RG_SOLVER_ADMM: friction-cone ADMM only (iteration cap admm_iters).
- * RG_SOLVER_ACTIVE_SET: exact dual active-set method only.
+/* RG_SOLVER_ADMM: friction-cone ADMM only (iteration cap admm_iters); unconverged robots are counted as failures.
+ * RG_SOLVER_ACTIVE_SET: exact dual active-set method only (horizon 10).
  * RG_SOLVER_AUTO: ADMM first; robots that have not converged after admm_iters iterations are
  *   re-solved exactly by the active-set kernel (second launch over a retry list). */
 enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1, RG_SOLVER_AUTO = 2 };
@@ -56,7 +56,7 @@ enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1, RG_SOLVER_AUTO = 2 };
  * upstream module defaults it does not override, as explicit fields. */
 typedef struct {
   int32_t abi_version;      /* RG_MPC_ABI_VERSION */
-  int32_t horizon;          /* upstream _PLANNING_HORIZON_STEPS = 10 */
+  int32_t horizon;          /* upstream _PLANNING_HORIZON_STEPS = 10; accepted: 10 and 20 (anything else is rejected by create) */
   double dt_plan;           /* upstream _PLANNING_TIMESTEP = 0.025 */
   double mass;              /* MPC_BODY_MASS      ghost/ctrl_constants.py:8 */
   double inertia[9];        /* MPC_BODY_INERTIA   ghost/ctrl_constants.py:9 (row-major) */
@@ -95,17 +95,19 @@ typedef struct {
   double ik_max_step;       /* rad per iteration */
   /* friction-cone ADMM */
   int32_t admm_iters;       /* ADMM iteration cap (300); exactly this many iterations when admm_tol == 0 */
-  int32_t reserved0;        /* tuning/A-B bits, 0 in production */
+  int32_t reserved0;        /* must be 0 */
   double admm_rho;          /* 1e-4 */
   double admm_relax;        /* 1.8 */
   double admm_tol;          /* stop when no z entry moved more than admm_tol * m * g over the last
                                admm_check iterations (1e-6); 0 = fixed iteration count */
   int32_t admm_check;       /* convergence check period (5) */
-  int32_t contact_lookahead;/* EXTENSION (not in upstream, default 0): horizon step k uses the open-loop desired contact
-                               state at t + k*dt_plan instead of holding the current contacts */
+  int32_t contact_lookahead;/* EXTENSION (not in upstream, default 0): horizon step k >= 1 uses a per-step contact schedule
+                               instead of holding the current contacts: the caller's
+                               rg_mpc_state_ptrs.contact_sched when given, else the open-loop desired contact state at
+                               t + k*dt_plan */
   int32_t warm_start;       /* opt-in (default 0): start ADMM from the robot's previous-tick (z, y) when its contact set is
                                unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve */
-  int32_t reserved2;
+  int32_t reserved2;        /* must be 0 */
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per
@@ -121,6 +123,10 @@ typedef struct {
                              columns 6+joint of calculateJacobian, controllers/mpc/kinematics.py:25-27,47-51 (kin_mode 0) */
   const int32_t *contact; /* [4][B] GetFootContacts                robot.py:215-229 */
   const float *cmd;       /* [3][B] (vx,vy,wz) AFTER the robot offsets of mpc_controller.py:90-95; NULL = use rg_mpc_set_command */
+  const int32_t *contact_sched; /* [4][B] optional, contact_lookahead only: bit k (1 <= k < horizon) of word [leg][b] = that leg
+                             is planned to be in contact at horizon step k (terrain / measured-contact knowledge of the caller;
+                             reference sources of contact variation: model/world/terrain.py:33-93, robot.py:215-229).  Bit 0 is
+                             ignored: step 0 is always the controller's own contact decision.  NULL = open-loop gait schedule */
 } rg_mpc_state_ptrs;
 
 typedef struct {
@@ -155,12 +161,27 @@ int rg_mpc_reset_at(rg_mpc_handle *h, const int32_t *idx_host, const double *t0_
  * pointer, offsets already added.  Copied into the handle. */
 int rg_mpc_set_command(rg_mpc_handle *h, const float *cmd, void *stream);
 
+/* Per-robot gait timing: the arguments of OpenloopGaitGenerator that _setup_controller takes from the robot's constants
+ * (mpc_controller.py:30-35: stance_duration, duty_factor, initial_leg_phase, initial_leg_state), one row per robot instead
+ * of one per handle.  Device pointers, float64 / int32, [4][B] each (leg-major); copied into the handle on `stream`.
+ * init_state may be NULL (config-wide initial states).  All four NULL returns to the config-wide gait.  Call it before
+ * rg_mpc_reset so that a reset starts from the new initial states.  A robot whose row is out of range
+ * (stance <= 0, duty outside (0, 1], non-finite phase, state not SWING/STANCE) is a counted failure each tick. */
+int rg_mpc_set_gait(rg_mpc_handle *h, const double *stance_duration, const double *duty_factor, const double *init_phase,
+                    const int32_t *init_state, void *stream);
+
 /* MPCController.get_action (mpc_controller.py:102-106) for all B robots at clock value t. */
 int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const rg_mpc_out_ptrs *out, void *stream);
 
 /* RobotMotorModel.convert_to_torque, HYBRID branch (model/robots/simple_motor.py:128-140):
  * action [B][60], q/qd [12][B] -> tau [B][12].  Device pointers. */
 int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream);
+
+/* The same motor model over the action-repeat loop of one control tick: the reference applies one 60-float command
+ * ACTION_REPEAT = 10 times (core/simulation.py:175-179, core/sim_constants.py:7), each time on the joint state of that
+ * simulation sub-step (robot.py:276-307 -> simple_motor.py:128-140).  q / qd [S][12][B] -> tau [S][B][12], S = substeps. */
+int rg_mpc_hybrid_to_torque_substeps(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau,
+                                     int32_t substeps, void *stream);
 
 /* Introspection for benches/profilers: number of robots per stance-leg count in the last
  * step (HOST out[5]); synchronises the stream. */
@@ -173,9 +194,9 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
 /* Solver statistics of the last step (synchronises the stream): sum and max of solver iterations
  * (ADMM iterations / active-set constraint additions) over the robots that had a QP, the number of
  * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO) and how many solves failed
- * (robots with a non-finite input or command, active-set breakdowns, plus robots ADMM left unconverged
- * where the plan has no exact re-solve pass: three and four stance legs at horizon 20 (incl. look-ahead
- * at horizon 20), RG_SOLVER_ADMM). */
+ * (robots with a non-finite input or an out-of-range gait row -- counted once, given an all-zero command row and
+ * left out of the QP --, active-set breakdowns, plus robots ADMM left unconverged where the plan has no exact
+ * re-solve pass: RG_SOLVER_ADMM, and three / four stance legs or a contact schedule at horizon 20). */
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);
 

@@ -67,8 +67,12 @@ class BatchedMPCController:
             raise RuntimeError("BatchedMPCController needs a HIP device (no CPU fallback)")
         self.cfg = cfg or MPCConfig.for_robot("ghost")
         self.batch = int(batch)
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self._handle = mpc_abi.MpcHandle(self.cfg, self.batch, self.device.index or 0)
+        dev = torch.device("cuda") if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError(f"BatchedMPCController runs on a HIP device, not {dev}")
+        # normalised to an explicit index: state tensors report cuda:N, and 'cuda' != 'cuda:0' for torch.device
+        self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
+        self._handle = mpc_abi.MpcHandle(self.cfg, self.batch, self.device.index)
         B, dev = self.batch, self.device
         self.cmd = torch.zeros(3, B, dtype=torch.float32, device=dev)
         self.action = torch.zeros(B, 60, dtype=torch.float32, device=dev)
@@ -123,8 +127,28 @@ class BatchedMPCController:
                 raise ValueError(f"state[{name!r}] must be contiguous {dt} [{comps},{self.batch}] on {self.device}")
             setattr(sp, name, tsr.data_ptr())
         sp.cmd = None  # use the command stored by update_controller_params
+        sched = state.get("contact_sched")
+        if sched is not None:
+            if sched.dtype != torch.int32 or tuple(sched.shape) != (4, self.batch) or not sched.is_contiguous() or sched.device != self.device:
+                raise ValueError(f"state['contact_sched'] must be contiguous int32 [4,{self.batch}] on {self.device}")
+            sp.contact_sched = sched.data_ptr()
         self._handle.step(t, sp, self._out, self._stream())
         return self.action
+
+    def set_gait(self, stance_duration=None, duty_factor=None, init_phase=None, init_state=None):
+        """Per-robot gait timing, [4,B] each (float64; init_state int32, optional): the OpenloopGaitGenerator arguments of
+        reference mpc_controller.py:30-35, one row per robot.  All None returns to the config-wide gait.  Call before reset()."""
+        if stance_duration is None and duty_factor is None and init_phase is None and init_state is None:
+            self._handle.set_gait(None, None, None, None, self._stream())
+            return
+        f = lambda a: torch.as_tensor(a, dtype=torch.float64).to(self.device).contiguous()
+        sd, du, ph = f(stance_duration), f(duty_factor), f(init_phase)
+        ist = None if init_state is None else torch.as_tensor(init_state, dtype=torch.int32).to(self.device).contiguous()
+        for a in (sd, du, ph) + (() if ist is None else (ist,)):
+            if tuple(a.shape) != (4, self.batch):
+                raise ValueError(f"gait arrays must be [4,{self.batch}]")
+        self._handle.set_gait(sd.data_ptr(), du.data_ptr(), ph.data_ptr(), None if ist is None else ist.data_ptr(), self._stream())
+        torch.cuda.current_stream(self.device).synchronize()   # the library copied from these temporaries
 
     def reset(self, idx=None, t0=0.0):
         """LocomotionController.reset for robots idx (None = all) -- reference mpc_controller.py:108-109."""
@@ -137,10 +161,20 @@ class BatchedMPCController:
         self._handle.reset_at(list(t0s), None if idx is None else list(idx), self._stream())
 
     def hybrid_to_torque(self, action, q, qd, out=None):
-        """Motor model, HYBRID branch (reference model/robots/simple_motor.py:128-140)."""
+        """Motor model, HYBRID branch (reference model/robots/simple_motor.py:128-140).
+        q, qd [12,B] -> tau [B,12]; or, for the S sub-steps of one control tick (the action-repeat loop of reference
+        core/simulation.py:175-179), q, qd [S,12,B] -> tau [S,B,12] in one launch."""
+        if q.shape != qd.shape or q.dtype != torch.float32 or qd.dtype != torch.float32 or not (q.is_contiguous() and qd.is_contiguous()):
+            raise ValueError("q and qd must be contiguous float32 tensors of one shape")
+        if q.dim() == 2 and tuple(q.shape) == (12, self.batch):
+            steps, shape = None, (self.batch, 12)
+        elif q.dim() == 3 and tuple(q.shape[1:]) == (12, self.batch):
+            steps, shape = int(q.shape[0]), (int(q.shape[0]), self.batch, 12)
+        else:
+            raise ValueError(f"q must be [12,{self.batch}] or [S,12,{self.batch}]")
         if out is None:
-            out = torch.empty(self.batch, 12, dtype=torch.float32, device=self.device)
-        self._handle.hybrid_to_torque(action.data_ptr(), q.data_ptr(), qd.data_ptr(), out.data_ptr(), self._stream())
+            out = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        self._handle.hybrid_to_torque(action.data_ptr(), q.data_ptr(), qd.data_ptr(), out.data_ptr(), self._stream(), substeps=steps)
         return out
 
     def solver_stats(self):

@@ -58,13 +58,14 @@ class MPCConfig:
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
     admm_iters: int = 300        # ADMM cap (robots beyond it go to the exact solver under SOLVER_AUTO); exact count when admm_tol == 0
-    reserved0: int = 0  # bit0: force the LDS-resident QP kernel (A/B, generic horizon path)
+    reserved0: int = 0           # must be 0 (rg_mpc_create rejects anything else)
     admm_rho: float = 1e-4
     admm_relax: float = 1.8
     admm_tol: float = 1e-6       # stop when no force moved more than admm_tol*m*g over admm_check iterations
     admm_check: int = 5          # convergence check period (5: -11 % iterations vs 10 at 6x the residual error, still 60x inside the tolerance)
-    contact_lookahead: int = 0   # extension: per-horizon-step contacts from the open-loop gait
+    contact_lookahead: int = 0   # extension: per-horizon-step contact schedule (caller-supplied, else from the open-loop gait)
     warm_start: int = 0          # opt-in: ADMM starts from the previous tick's (z, y) when the contact set is unchanged
+    reserved2: int = 0           # must be 0
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

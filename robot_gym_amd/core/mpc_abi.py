@@ -12,7 +12,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
 # RG_MPC_LIB: load another build of the same C-ABI (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("RG_MPC_LIB") or os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 d = C.c_double
 i32 = C.c_int32
 fp = C.c_void_p
@@ -39,14 +39,15 @@ class CConfig(C.Structure):
 
 
 class CStatePtrs(C.Structure):
-    _fields_ = [(n, fp) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact", "cmd")]
+    _fields_ = [(n, fp) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact", "cmd", "contact_sched")]
 
 
 class COutPtrs(C.Structure):
     _fields_ = [(n, fp) for n in ("action", "grf", "tau_stance", "leg_state", "desired_state", "phase", "foot_target", "v_body")]
 
 
-EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
+EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_set_gait", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
+           "rg_mpc_hybrid_to_torque_substeps",
            "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
@@ -75,6 +76,10 @@ def load_library(path=None):
     L.rg_mpc_step.restype = i32
     L.rg_mpc_hybrid_to_torque.argtypes = [fp, fp, fp, fp, fp, fp]
     L.rg_mpc_hybrid_to_torque.restype = i32
+    L.rg_mpc_hybrid_to_torque_substeps.argtypes = [fp, fp, fp, fp, fp, i32, fp]
+    L.rg_mpc_hybrid_to_torque_substeps.restype = i32
+    L.rg_mpc_set_gait.argtypes = [fp, fp, fp, fp, fp, fp]
+    L.rg_mpc_set_gait.restype = i32
     L.rg_mpc_last_bin_counts.argtypes = [fp, C.POINTER(i32 * 5), fp]
     L.rg_mpc_last_bin_counts.restype = i32
     L.rg_mpc_last_solver_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), fp]
@@ -112,7 +117,7 @@ def make_cconfig(cfg):
     c = CConfig()
     c.abi_version = ABI_VERSION
     for name, ctype in CConfig._fields_:
-        if name in ("abi_version", "reserved2"):
+        if name == "abi_version":
             continue
         v = getattr(cfg, name)
         if isinstance(v, (tuple, list)) or hasattr(v, "__len__"):
@@ -164,8 +169,14 @@ class MpcHandle:
     def step(self, t, state_ptrs: CStatePtrs, out_ptrs: COutPtrs, stream=None):
         self._check(self._lib.rg_mpc_step(self._h, float(t), C.byref(state_ptrs), C.byref(out_ptrs), stream))
 
-    def hybrid_to_torque(self, action_ptr, q_ptr, qd_ptr, tau_ptr, stream=None):
-        self._check(self._lib.rg_mpc_hybrid_to_torque(self._h, action_ptr, q_ptr, qd_ptr, tau_ptr, stream))
+    def set_gait(self, stance_ptr, duty_ptr, phase_ptr, init_state_ptr=None, stream=None):
+        self._check(self._lib.rg_mpc_set_gait(self._h, stance_ptr, duty_ptr, phase_ptr, init_state_ptr, stream))
+
+    def hybrid_to_torque(self, action_ptr, q_ptr, qd_ptr, tau_ptr, stream=None, substeps=None):
+        if substeps is None:
+            self._check(self._lib.rg_mpc_hybrid_to_torque(self._h, action_ptr, q_ptr, qd_ptr, tau_ptr, stream))
+        else:
+            self._check(self._lib.rg_mpc_hybrid_to_torque_substeps(self._h, action_ptr, q_ptr, qd_ptr, tau_ptr, int(substeps), stream))
 
     def last_bin_counts(self, stream=None):
         out = (i32 * 5)()

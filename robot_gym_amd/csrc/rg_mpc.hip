@@ -1,14 +1,18 @@
-// rg_mpc.hip -- MI355X (gfx950) batched convex-MPC gait controller: kernels + C-ABI.
+// rg_mpc.hip -- MI355X (gfx950) batched convex-MPC gait controller: C-ABI host side + small kernels.
 //
 // Path: one control tick of robot-gym's MPCController.get_action()
-// (reference robot_gym/controllers/mpc/mpc_controller.py:102-106) for B robots:
-//   rg_front_kernel   lane = robot, coalesced SoA reads: gait phase, CoM velocity filter,
-//                     Raibert swing foothold + trajectory + IK, stance-QP record, binning
-//                     of robots by number of stance legs.
-//   rg_qp_admm_kernel one robot per workgroup (1 wave for <=64 QP variables, 2 above):
-//                     closed-form condensed QP assembly (Kronecker structure), in-LDS
-//                     symmetric sweep inversion of (P + rho I), fixed-count over-relaxed
-//                     ADMM with exact friction-pyramid projection, J' f, 60-float action.
+// (reference robot_gym/controllers/mpc/mpc_controller.py:102-106) for B robots.  Launch plan per tick:
+//   rg_front_kernel            one lane per (robot, leg), coalesced SoA reads: gait phase, CoM velocity filter,
+//                              Raibert swing foothold + trajectory + IK, the stance-QP record, and the work lists
+//                              (cost classes predicted from each robot's previous-tick iteration count).
+//   rg_qp_fused_kernel<H>      one workgroup per robot (one wave at H = 10, 256 lanes at H = 20), every stance-leg
+//                              count in one launch: closed-form Kronecker QP assembly, in-register symmetric sweep
+//                              inverse, over-relaxed friction-pyramid ADMM (force space for 1-2 legs, wrench space
+//                              for 3-4 legs and for contact schedules), J' f, 60-float action row.
+//   rg_qp_fused_retry_kernel / rg_qp_admm_tile_kernel<..., true>
+//                              exact dual active-set re-solve of the robots ADMM left unconverged (RG_SOLVER_AUTO),
+//                              or of every robot (RG_SOLVER_ACTIVE_SET).
+// Every accepted configuration has a GPU-tested instantiation; anything else is rejected by rg_mpc_create.
 // No MFMA: the per-robot blocks are 6..12 wide and every robot has its own operands.
 #include "rg_mpc_dev.h"
 #include "../../include/rg_mpc.h"
@@ -20,8 +24,6 @@
 
 #include "rg_front_kernel.inc"
 #include "rg_qp_common.inc"
-#include "rg_qp_lds_kernel.inc"
-#include "rg_qp_row_kernel.inc"
 #include "rg_qp_tile_kernel.inc"
 #include "rg_qp_wrench_kernel.inc"
 #include "rg_qp_fused_kernel.inc"
@@ -37,7 +39,7 @@ __global__ void rg_reset_kernel(const DevCfg *__restrict__ c, DevState st, const
   st.reset_time[b] = t0v ? t0v[k] : t0;
   st.flags[b] = 3;
   int ld = 0;
-  for (int l = 0; l < 4; l++) ld |= (c->init_state[l] & 1) << l;
+  for (int l = 0; l < 4; l++) ld |= ((st.g_init ? st.g_init[l * B + b] : c->init_state[l]) & 1) << l;
   st.last_desired[b] = ld;
   st.ring_len[b] = 0; st.ring_head[b] = 0;
   for (int a = 0; a < 3; a++) { st.fsum[a * B + b] = 0.0; st.fcorr[a * B + b] = 0.0; }
@@ -45,16 +47,22 @@ __global__ void rg_reset_kernel(const DevCfg *__restrict__ c, DevState st, const
   st.warm_key[b] = -1;
 }
 
-// RobotMotorModel.convert_to_torque HYBRID (reference model/robots/simple_motor.py:128-140)
+// RobotMotorModel.convert_to_torque HYBRID (reference model/robots/simple_motor.py:128-140), for S consecutive
+// simulation sub-steps of one control tick: the reference applies the same 60-float command ACTION_REPEAT (10) times,
+// each time with fresh joint angles and velocities (core/simulation.py:175-179 -> robot.py:276-307).
+// q / qd [S][12][B] -> tau [S][B][12]; the command row is read once per (robot, joint) lane and kept in registers.
 __global__ void rg_hybrid_to_torque_kernel(const float *__restrict__ action, const float *__restrict__ q,
-                                           const float *__restrict__ qd, float *__restrict__ tau, int B) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+                                           const float *__restrict__ qd, float *__restrict__ tau, int B, int S) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B * 12) return;
-  int b = e / 12, j = e % 12;
+  const int j = e / B, b = e - j * B;   // lane = robot: q / qd loads coalesce
   const float *a = action + (size_t)b * 60 + 5 * j;
-  double qs = a[0], kp = a[1], qds = a[2], kd = a[3], ff = a[4];
-  double t = -1.0 * (kp * ((double)q[j * B + b] - qs)) - kd * ((double)qd[j * B + b] - qds) + ff;
-  tau[e] = (float)t;
+  const double qs = a[0], kp = a[1], qds = a[2], kd = a[3], ff = a[4];
+  for (int s = 0; s < S; s++) {
+    const size_t in = ((size_t)s * 12 + j) * B + b;
+    const double t = -1.0 * (kp * ((double)q[in] - qs)) - kd * ((double)qd[in] - qds) + ff;
+    tau[((size_t)s * B + b) * 12 + j] = (float)t;
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -69,24 +77,18 @@ struct rg_mpc_handle {
   int *idx_dev = nullptr;
   double *t0_dev = nullptr;
   int cu_count = 256;
-  size_t lds_bytes[5] = {0, 0, 0, 0, 0};
   std::vector<void *> allocs;
   std::string err;
   // optional per-kernel event timing
   std::vector<hipEvent_t> ev;   // RG_PROF_EV events per profiled step
   int prof_max = 0, prof_n = 0, prof_stride = 1;   // events are recorded on every prof_stride-th step
   long long tick = 0;
-  bool force_lds_kernel = false;
-  int qp_variant = 0;
-  bool wrench_space = true;         // 3-4 stance legs: ADMM in wrench coordinates (reserved0 bit4 = force-space kernel, A/B)
-  bool fused = false;               // H = 10 / 20, ADMM: one launch for all stance-leg counts (reserved0 bit5 = per-count launches, A/B)
-  bool grid_per_robot = true;       // fused launch: one workgroup per robot, longest first (reserved0 bit6 = 8 workgroups per CU looping, A/B: 3 % slower)
+  bool fused = false;               // ADMM plans (RG_SOLVER_ADMM / RG_SOLVER_AUTO): one launch for all stance-leg counts
   int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
-  bool auto_retry = false;          // RG_SOLVER_AUTO with an active-set instantiation available
-  int retry_max_nc = 0;             // ... for robots with up to this many stance legs (4 at horizon 10, 2 at horizon 20)
-  bool concurrent_bins = false;     // opt-in: run the per-stance-count QP launches on forked streams
-  hipStream_t aux[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_front = nullptr, ev_done[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool auto_retry = false;          // RG_SOLVER_AUTO: robots ADMM left unconverged are re-solved exactly
+  int retry_max_nc = 0;             // ... for robots with up to this many stance legs
+  double *gait_buf = nullptr;       // [3][4][B] per-robot stance duration / duty factor / initial phase (rg_mpc_set_gait)
+  int *gait_init_buf = nullptr;     // [4][B] per-robot initial leg state
 };
 
 static thread_local std::string g_create_err;
@@ -114,14 +116,16 @@ static void rot_zyx_host(const double *rpy, double *R) {
 static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memset(d, 0, sizeof(*d));
   if (c->abi_version != RG_MPC_ABI_VERSION) { err = "abi_version mismatch"; return RG_MPC_ERR_INVALID; }
-  if (c->horizon < 1 || c->horizon > RG_MAXH) { err = "horizon out of range [1,20]"; return RG_MPC_ERR_INVALID; }
+  // the reference cannot set the horizon at all (mpc_controller.py:47-56 passes none: upstream default 10); 10 and 20
+  // (BASELINE configs[4]) are the horizons with compiled and GPU-tested solver bodies
+  if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
+  if (c->reserved0 != 0 || c->reserved2 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
-  if (c->solver == RG_SOLVER_ACTIVE_SET && ((c->reserved0 & 7) != 0 || c->horizon != 10)) { err = "the active-set solver needs the tiled QP kernel and horizon 10"; return RG_MPC_ERR_INVALID; }
-  if (c->contact_lookahead && ((c->reserved0 & 7) != 0 || (c->horizon != 10 && c->horizon != 20))) { err = "contact_lookahead needs the tiled QP kernel (reserved0 bits 0-2 clear) and horizon 10 or 20"; return RG_MPC_ERR_INVALID; }
+  if (c->solver == RG_SOLVER_ACTIVE_SET && c->horizon != 10) { err = "RG_SOLVER_ACTIVE_SET (every robot solved exactly) needs horizon 10"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 12; i++) if (!(c->motor_dir[i] == 1.0 || c->motor_dir[i] == -1.0)) { err = "motor_dir must be +-1"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 4; i++) {
@@ -174,12 +178,6 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   return RG_MPC_OK;
 }
 
-static size_t qp_lds_bytes(int nc, int H) {
-  size_t m3 = 3 * nc, n = m3 * H, LD = n | 1;
-  size_t dbl = n * LD + 2 * n + 2 * m3 * m3 + 2 * H * m3 + 6 * m3 + RG_REC_N + 24;
-  return dbl * sizeof(double);
-}
-
 template <typename T>
 static int dev_alloc(rg_mpc_handle *h, T **p, size_t count) {
   void *v = nullptr;
@@ -195,25 +193,23 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,rg_qp_admm_tile_kernel,rg_qp_wrench_kernel,rg_qp_admm_reg_kernel,rg_qp_admm_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,rg_qp_admm_tile_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mpc_handle **out) {
   if (!cfg || !out || batch < 1) { g_create_err = "null config/out or batch < 1"; return RG_MPC_ERR_INVALID; }
+  if (batch > (1 << 24)) { g_create_err = "batch > 2^24 robots per handle (work-list entries pack robot | stance legs << 24)"; return RG_MPC_ERR_INVALID; }
   *out = nullptr;
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
-  h->force_lds_kernel = (cfg->reserved0 & 1) != 0;
-  // exact re-solve pass: every stance-leg count at horizon 10 (also under contact look-ahead, where every robot
-  // solves the four-leg problem), one and two legs at horizon 20 (n <= 120)
-  h->auto_retry = cfg->solver == RG_SOLVER_AUTO && (cfg->reserved0 & 7) == 0 && (cfg->horizon == 10 || (cfg->horizon == 20 && !cfg->contact_lookahead));
-  h->retry_max_nc = !h->auto_retry ? 0 : (cfg->horizon == 10 ? 4 : 2);
-  h->qp_variant = (cfg->reserved0 >> 1) & 3;
-  h->wrench_space = ((cfg->reserved0 >> 4) & 1) == 0;
-  h->fused = h->wrench_space && ((cfg->reserved0 >> 5) & 1) == 0 && (cfg->reserved0 & 15) == 0 && (cfg->horizon == 10 || cfg->horizon == 20) && cfg->solver != RG_SOLVER_ACTIVE_SET;
-  h->grid_per_robot = ((cfg->reserved0 >> 6) & 1) == 0;
-  h->concurrent_bins = ((cfg->reserved0 >> 3) & 1) != 0;  // bit3: fork the QP launches onto internal streams (measured slower: the bins compete for the same LDS/VALU)         // bits1-2: register-kernel tiling variant (tuning A/B)  // bit0: use the LDS-resident QP kernel (A/B and generic-H path)
+  // Launch plans.  ADMM solvers: front -> fused QP launch -> exact re-solves (RG_SOLVER_AUTO).  RG_SOLVER_ACTIVE_SET
+  // (horizon 10): front -> one exact launch per stance-leg count.
+  h->fused = cfg->solver != RG_SOLVER_ACTIVE_SET;
+  h->auto_retry = cfg->solver == RG_SOLVER_AUTO;
+  // exact re-solve bodies exist for every stance-leg count at horizon 10 (also under a contact schedule) and for one and
+  // two legs at horizon 20; robots outside that set which ADMM leaves unconverged are counted as failures
+  h->retry_max_nc = !h->auto_retry ? 0 : (cfg->horizon == 10 ? 4 : (cfg->contact_lookahead ? 0 : 2));
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   h->hcfg.plan = h->fused ? 1 : 0;
   if (rc) { g_create_err = h->err; delete h; return rc; }
@@ -238,19 +234,6 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.warm_key, B); AL(h->st.bins, RG_NLISTS * B); AL(h->counts2, 2 * RG_NCOUNTS); AL(h->st.iters, B); AL(h->st.ncs, B);
   h->st.counts = h->counts2; h->st.counts_next = h->counts2 + RG_NCOUNTS;
   AL(h->idx_dev, B); AL(h->t0_dev, B);
-  CR(hipEventCreateWithFlags(&h->ev_front, hipEventDisableTiming));
-  for (int nc = 1; nc <= 4; nc++) {
-    CR(hipStreamCreateWithFlags(&h->aux[nc], hipStreamNonBlocking));
-    CR(hipEventCreateWithFlags(&h->ev_done[nc], hipEventDisableTiming));
-  }
-  for (int nc = 1; nc <= 4; nc++) {
-    size_t bytes = qp_lds_bytes(nc, cfg->horizon);
-    h->lds_bytes[nc] = bytes;
-    if (bytes > 160 * 1024) { h->lds_bytes[nc] = 0; continue; } // unsupported size: rejected at step time if it occurs
-    if (3 * nc * cfg->horizon <= 64) CR(hipFuncSetAttribute((const void *)rg_qp_admm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    else if (3 * nc * cfg->horizon <= 128) CR(hipFuncSetAttribute((const void *)rg_qp_admm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    else CR(hipFuncSetAttribute((const void *)rg_qp_admm_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  }
 #undef CR
 #undef AL
   *out = h;
@@ -268,11 +251,6 @@ void rg_mpc_destroy(rg_mpc_handle *h) {
   (void)hipSetDevice(h->device);
   for (void *p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-  if (h->ev_front) (void)hipEventDestroy(h->ev_front);
-  for (int nc = 1; nc <= 4; nc++) {
-    if (h->ev_done[nc]) (void)hipEventDestroy(h->ev_done[nc]);
-    if (h->aux[nc]) (void)hipStreamDestroy(h->aux[nc]);
-  }
   delete h;
 }
 
@@ -317,15 +295,41 @@ int rg_mpc_set_command(rg_mpc_handle *h, const float *cmd, void *stream) {
   return RG_MPC_OK;
 }
 
+int rg_mpc_set_gait(rg_mpc_handle *h, const double *stance_duration, const double *duty_factor, const double *init_phase,
+                    const int32_t *init_state, void *stream) {
+  if (!h) return RG_MPC_ERR_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n4 = (size_t)4 * h->B;
+  if (!stance_duration && !duty_factor && !init_phase && !init_state) {   // back to the config-wide gait
+    h->st.g_stance = h->st.g_duty = h->st.g_phase = nullptr; h->st.g_init = nullptr;
+    return RG_MPC_OK;
+  }
+  if (!stance_duration || !duty_factor || !init_phase) { h->err = "set_gait: stance_duration, duty_factor and init_phase go together (init_state is optional)"; return RG_MPC_ERR_INVALID; }
+  if (!h->gait_buf) {
+    int r_ = dev_alloc(h, &h->gait_buf, 3 * n4); if (r_) return r_;
+    r_ = dev_alloc(h, &h->gait_init_buf, n4); if (r_) return r_;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->gait_buf, stance_duration, sizeof(double) * n4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->gait_buf + n4, duty_factor, sizeof(double) * n4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->gait_buf + 2 * n4, init_phase, sizeof(double) * n4, hipMemcpyDeviceToDevice, s));
+  if (init_state) HIPCHK(h, hipMemcpyAsync(h->gait_init_buf, init_state, sizeof(int) * n4, hipMemcpyDeviceToDevice, s));
+  // validated on the device (a bad entry makes its robot a counted failure every tick, like a non-finite state)
+  h->st.g_stance = h->gait_buf; h->st.g_duty = h->gait_buf + n4; h->st.g_phase = h->gait_buf + 2 * n4;
+  h->st.g_init = init_state ? h->gait_init_buf : nullptr;
+  return RG_MPC_OK;
+}
+
 int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const rg_mpc_out_ptrs *out, void *stream) {
   if (!h || !in || !out) { if (h) h->err = "step: null argument"; return RG_MPC_ERR_INVALID; }
   if (!in->rpy || !in->rpy_rate || !in->v_world || !in->quat || !in->q || !in->contact) { h->err = "step: missing required state pointer"; return RG_MPC_ERR_INVALID; }
   if (h->cfg.kin_mode == 0 && (!in->foot_pos || !in->jac)) { h->err = "step: kin_mode 0 needs foot_pos and jac"; return RG_MPC_ERR_INVALID; }
   if (!out->action) { h->err = "step: action output required"; return RG_MPC_ERR_INVALID; }
+  if (in->contact_sched && !h->cfg.contact_lookahead) { h->err = "step: contact_sched needs contact_lookahead = 1 in the config"; return RG_MPC_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
   const int B = h->B, H = h->cfg.horizon;
-  DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact};
+  DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact, in->contact_sched};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
   { int *t_ = h->st.counts; h->st.counts = h->st.counts_next; h->st.counts_next = t_; }   // this tick's counters were zeroed by the previous tick's front kernel
   hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
@@ -333,70 +337,29 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);   // one wave per workgroup: 16 k lanes spread over all CUs
   HIPCHK(h, hipGetLastError());
   if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
-  // Robots with different stance-leg counts are independent; optionally (reserved0 bit3) the four QP
-  // launches are forked onto internal streams and joined back into the caller's stream.  Measured
-  // on MI355X this is ~8 % slower than back-to-back launches, so it is off by default.
   if (h->fused) {
-    // horizon 10 / 20, ADMM: one launch over all stance-leg counts, then (horizon 10) the normally empty exact re-solves
+    // ADMM plans: one launch over all stance-leg counts, then the (normally empty) exact re-solve lists
     // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
-    HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s, h->grid_per_robot));
+    HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
     if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
     else if (h->auto_retry) {
       for (int nc = h->retry_max_nc; nc >= 1; nc--) {
         hipError_t lerr;
-        launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2);
+        if (!launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2)) { h->err = "step: no exact re-solve body for this (horizon, stance legs)"; return RG_MPC_ERR_INVALID; }
         HIPCHK(h, lerr);
       }
     }
     if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
     return RG_MPC_OK;
   }
-  const bool fork = h->concurrent_bins;
-  if (fork) HIPCHK(h, hipEventRecord(h->ev_front, s));
-  const int order[4] = {4, 2, 3, 1};  // longest first
-  for (int oi = 0; oi < 4; oi++) {
-    const int nc = fork ? order[oi] : oi + 1;
-    const int n = 3 * nc * H;
-    hipStream_t qs = s;
-    if (fork) { qs = h->aux[nc]; HIPCHK(h, hipStreamWaitEvent(qs, h->ev_front, 0)); }
-    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc], qs));
-    bool launched = false;
-    if (!h->force_lds_kernel && h->qp_variant != 2 && h->qp_variant != 1) {
-      hipError_t lerr;
-      const bool exact = h->cfg.solver == RG_SOLVER_ACTIVE_SET;
-      if ((!exact && h->wrench_space && launch_qp_wrench_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr)) ||
-          launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, exact ? 1 : 0)) {
-        HIPCHK(h, lerr);
-        launched = true;
-        if (h->auto_retry && nc <= h->retry_max_nc) {   // exact re-solve of the robots ADMM left unconverged
-          launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr, 2);
-          HIPCHK(h, lerr);
-        }
-      }
-    }
-    if (!launched && !h->force_lds_kernel) {
-      hipError_t lerr;
-      if (launch_qp_reg_dispatch(h->qp_variant, nc, H, h->dcfg, h->st, dout, B, h->cu_count, qs, &lerr)) {
-        HIPCHK(h, lerr);
-        launched = true;
-      }
-    }
-    size_t lds = h->lds_bytes[nc];
-    if (!launched && lds != 0) {
-      int per_cu = (int)((160 * 1024) / lds);
-      if (per_cu < 1) per_cu = 1;
-      if (per_cu > 8) per_cu = 8;
-      int grid = h->cu_count * per_cu;
-      if (grid > B) grid = B;
-      if (n <= 64) hipLaunchKernelGGL(rg_qp_admm_kernel<64>, dim3(grid), dim3(64), lds, qs, h->dcfg, h->st, dout, nc, B);
-      else if (n <= 128) hipLaunchKernelGGL(rg_qp_admm_kernel<128>, dim3(grid), dim3(128), lds, qs, h->dcfg, h->st, dout, nc, B);
-      else hipLaunchKernelGGL(rg_qp_admm_kernel<256>, dim3(grid), dim3(256), lds, qs, h->dcfg, h->st, dout, nc, B);
-      HIPCHK(h, hipGetLastError());
-    }
-    // (no instantiation and no LDS fit: H = 20 with 3-4 stance legs -- robots of that bin keep their previous action)
-    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc + 1], qs));
-    if (fork) { HIPCHK(h, hipEventRecord(h->ev_done[nc], qs)); HIPCHK(h, hipStreamWaitEvent(s, h->ev_done[nc], 0)); }
+  // RG_SOLVER_ACTIVE_SET: one exact launch per stance-leg count
+  for (int nc = 1; nc <= 4; nc++) {
+    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc], s));
+    hipError_t lerr;
+    if (!launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 1)) { h->err = "step: no exact solver body for this (horizon, stance legs)"; return RG_MPC_ERR_INVALID; }
+    HIPCHK(h, lerr);
+    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc + 1], s));
   }
   if (pev) HIPCHK(h, hipEventRecord(pev[10], s));
   if (pev) h->prof_n++;
@@ -479,13 +442,18 @@ int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream) {
   return RG_MPC_OK;
 }
 
-int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream) {
+int rg_mpc_hybrid_to_torque_substeps(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, int32_t substeps, void *stream) {
   if (!h || !action || !q || !qd || !tau) { if (h) h->err = "hybrid_to_torque: null pointer"; return RG_MPC_ERR_INVALID; }
+  if (substeps < 1 || substeps > 1024) { h->err = "hybrid_to_torque: substeps out of range [1,1024]"; return RG_MPC_ERR_INVALID; }
   HIPCHK(h, hipSetDevice(h->device));
-  int total = h->B * 12;
-  hipLaunchKernelGGL(rg_hybrid_to_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, action, q, qd, tau, h->B);
+  const int total = h->B * 12;
+  hipLaunchKernelGGL(rg_hybrid_to_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, action, q, qd, tau, h->B, substeps);
   HIPCHK(h, hipGetLastError());
   return RG_MPC_OK;
+}
+
+int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream) {
+  return rg_mpc_hybrid_to_torque_substeps(h, action, q, qd, tau, 1, stream);
 }
 
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,

@@ -1,7 +1,8 @@
 // rg_mpc_dev.h -- device-side types and math for the batched convex-MPC controller (gfx950).
-// Everything here is float64: the condensed QP Hessian has condition number ~4e5
-// (alpha = 1e-5 against O(1) angular terms) and CDNA4 issues v_fma_f64 at half the
-// packed-f32 rate, so f64 costs < 2x and buys the 1e-4 torque tolerance with margin.
+// Everything here is float64: the condensed QP Hessian has condition number ~4e5 (alpha = 1e-5 against O(1)
+// angular terms), which float32 cannot carry to the 1e-4 torque tolerance.  CDNA4 issues v_fma_f64 at 4 cycles
+// per wave instruction -- the issue cost one wave pays for a (non-packed) f32 FMA too -- so float64 costs register
+// space (two VGPRs per value), not issue slots ("Precision").
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -78,11 +79,15 @@ struct DevState {
   int *ncs;             // [B] stance-leg count of each robot in the last tick
   int *counts_next;     // [RG_NCOUNTS] the other half of the double-buffered counters: zeroed by the front kernel for the next tick (no memset node)
   int *iters;           // [B] solver iterations of the last tick (ADMM, plus the exact re-solve's if it ran)
+  // optional per-robot gait timing (rg_mpc_set_gait), [4][B] each; null = the config-wide gait of DevCfg
+  const double *g_stance, *g_duty, *g_phase;
+  const int *g_init;
 };
 
 struct DevIn {
   const float *rpy, *rpy_rate, *v_world, *quat, *q, *foot_pos, *jac, *cmd;
   const int *contact;
+  const int *contact_sched;   // [4][B] optional caller-supplied contact schedule (bit k = in contact at horizon step k)
 };
 struct DevOut {
   float *action, *grf, *tau_stance, *phase, *foot_target, *v_body;

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     lib = mpc_abi.load_library()
-    assert lib.rg_mpc_abi_version() == mpc_abi.ABI_VERSION == 1
+    assert lib.rg_mpc_abi_version() == mpc_abi.ABI_VERSION == 2
     assert lib.rg_mpc_config_size() == C.sizeof(mpc_abi.CConfig)
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     bodies = {name: body for body, name in re.findall(r"typedef struct \{([^{}]*)\} (\w+);", src)}
@@ -63,16 +63,22 @@ def test_create_fails_loudly_without_gpu():
 
 def test_create_rejects_bad_config_before_touching_the_gpu():
     lib = mpc_abi.load_library()
-    for bad in (dict(horizon=0), dict(horizon=21), dict(mu=(0.45, 0.45, 0.4, 0.45)), dict(window=0), dict(kin_mode=2),
+    # horizons: only 10 and 20 have compiled, GPU-tested solver bodies -- everything else must be refused here, never
+    # accepted and then silently not solved (round-1 finding: horizons 11-19 could leave a stance-leg bin unlaunched)
+    for bad in (dict(horizon=0), dict(horizon=21), dict(horizon=5), dict(horizon=12), dict(horizon=15), dict(horizon=16),
+                dict(mu=(0.45, 0.45, 0.4, 0.45)), dict(window=0), dict(kin_mode=2),
                 dict(solver=7), dict(admm_relax=2.5), dict(motor_dir=(0.5,) * 12), dict(inertia=(0.0,) * 9),
                 dict(solver=1, horizon=20), dict(solver=1, contact_lookahead=1, horizon=20), dict(contact_lookahead=1, horizon=12),
-                dict(contact_lookahead=1, reserved0=2), dict(admm_tol=-1.0), dict(admm_check=0)):
+                dict(reserved0=1), dict(reserved0=32), dict(reserved2=1), dict(admm_tol=-1.0), dict(admm_check=0)):
         cc = mpc_abi.make_cconfig(MPCConfig.for_robot("ghost", **bad))
         h = C.c_void_p()
         rc = lib.rg_mpc_create(C.byref(cc), 4, 0, C.byref(h))
         assert rc == -1 and not h.value, bad
         assert lib.rg_mpc_last_error(None)
     assert lib.rg_mpc_create(None, 4, 0, C.byref(C.c_void_p())) == -1
+    cc = mpc_abi.make_cconfig(MPCConfig.for_robot("ghost"))
+    assert lib.rg_mpc_create(C.byref(cc), (1 << 24) + 1, 0, C.byref(C.c_void_p())) == -1   # work-list entries pack robot | legs << 24
+    assert b"2^24" in lib.rg_mpc_last_error(None)
 
 
 def test_product_path_never_imports_the_oracle():
