@@ -127,6 +127,10 @@ typedef struct {
                              is planned to be in contact at horizon step k (terrain / measured-contact knowledge of the caller;
                              reference sources of contact variation: model/world/terrain.py:33-93, robot.py:215-229).  Bit 0 is
                              ignored: step 0 is always the controller's own contact decision.  NULL = open-loop gait schedule */
+  const double *t_robot;  /* [B] optional per-robot clock values (float64): robot b is stepped at t_robot[b] instead of the
+                             scalar t of rg_mpc_step -- every reference controller reads its OWN simulation's clock
+                             (controllers/controller.py:6-8, core/simulation.py:141-142), and sub-envs of a vectorised env that
+                             were reset at different moments are at different clock values.  NULL = all robots at t */
 } rg_mpc_state_ptrs;
 
 typedef struct {

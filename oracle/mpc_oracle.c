@@ -680,7 +680,8 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
     int *sched = malloc(sizeof(int) * 4 * H), nb = 0;
     for (int k = 0; k < H; k++) {
       int des[4];
-      orc_gait_desired(c, t + k * c->dt_plan, des);
+      if (in->sched_valid) { for (int l = 0; l < 4; l++) des[l] = ((in->sched[l] >> k) & 1) ? ORC_STANCE : ORC_SWING; }   /* caller's schedule */
+      else orc_gait_desired(c, t + k * c->dt_plan, des);
       for (int l = 0; l < 4; l++) { sched[k * 4 + l] = (des[l] == ORC_STANCE); nb += sched[k * 4 + l]; }
     }
     for (int l = 0; l < 4; l++) sched[l] = contact[l];
@@ -731,6 +732,18 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
   for (int leg = 0; leg < 4; leg++) { out->desired[leg] = s->desired[leg]; out->leg_state[leg] = s->leg_state[leg]; out->phase[leg] = s->phase[leg]; }
   memcpy(out->v_body, s->v_body, sizeof(double) * 3);
   return 0;
+}
+
+int orc_step_batch_cfgs(const orc_config *cfgs, orc_state *s, int B, double t_now, const orc_input *in, orc_output *out, int nthreads) {
+  int bad = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : bad)
+  for (int b = 0; b < B; b++) if (orc_step(&cfgs[b], &s[b], t_now, &in[b], &out[b])) bad++;
+  return bad;
 }
 
 int orc_step_batch(const orc_config *c, orc_state *s, int B, double t_now, const orc_input *in, orc_output *out, int nthreads) {

@@ -99,6 +99,10 @@ typedef struct {
   double jac[4][3][3];      /* d foot / d leg joints, base frame (kin_mode 0) */
   int contact[4];           /* REF robot.py:215-229 */
   double cmd[3];            /* vx, vy, wz AFTER offsets, REF mpc_controller.py:90-95 */
+  /* EXTENSION (contact_lookahead only): caller-supplied contact schedule.  sched_valid != 0: bit k (1 <= k < H) of
+   * sched[leg] = leg in contact at horizon step k; bit 0 is ignored (step 0 = the controller's own contact decision). */
+  int sched_valid;
+  int sched[4];
 } orc_input;
 
 typedef struct {
@@ -146,6 +150,8 @@ int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk 
 
 /* batch helpers (OpenMP over robots) */
 int orc_step_batch(const orc_config *c, orc_state *s, int B, double t_now, const orc_input *in, orc_output *out, int nthreads);
+/* same with one config per robot (per-robot gait timing: BASELINE config 5 draws a random duty factor per robot) */
+int orc_step_batch_cfgs(const orc_config *cfgs, orc_state *s, int B, double t_now, const orc_input *in, orc_output *out, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ class Input(C.Structure):
     _fields_ = [
         ("rpy", d * 3), ("rpy_rate", d * 3), ("v_world", d * 3), ("quat", d * 4), ("q", d * 12),
         ("foot_pos", (d * 3) * 4), ("jac", ((d * 3) * 3) * 4), ("contact", i32 * 4), ("cmd", d * 3),
+        ("sched_valid", i32), ("sched", i32 * 4),
     ]
 
 
@@ -57,7 +58,8 @@ class Output(C.Structure):
 
 INPUT_DTYPE = np.dtype([
     ("rpy", "f8", 3), ("rpy_rate", "f8", 3), ("v_world", "f8", 3), ("quat", "f8", 4), ("q", "f8", 12),
-    ("foot_pos", "f8", (4, 3)), ("jac", "f8", (4, 3, 3)), ("contact", "i4", 4), ("cmd", "f8", 3)], align=True)
+    ("foot_pos", "f8", (4, 3)), ("jac", "f8", (4, 3, 3)), ("contact", "i4", 4), ("cmd", "f8", 3),
+    ("sched_valid", "i4"), ("sched", "i4", 4)], align=True)
 OUTPUT_DTYPE = np.dtype([
     ("action", "f4", 60), ("grf", "f8", 12), ("tau", "f8", 12), ("desired", "i4", 4), ("leg_state", "i4", 4),
     ("phase", "f8", 4), ("v_body", "f8", 3), ("foot_target", "f8", (4, 3)), ("qp_iters", "i4"), ("kkt", "f8", 3)],
@@ -84,6 +86,8 @@ def lib():
         L.orc_step.restype = i32
         L.orc_step_batch.argtypes = [C.POINTER(Config), C.c_void_p, i32, d, C.c_void_p, C.c_void_p, i32]
         L.orc_step_batch.restype = i32
+        L.orc_step_batch_cfgs.argtypes = [C.c_void_p, C.c_void_p, i32, d, C.c_void_p, C.c_void_p, i32]
+        L.orc_step_batch_cfgs.restype = i32
         L.orc_gait.argtypes = [C.POINTER(Config), d, C.POINTER(i32 * 4), C.POINTER(i32 * 4), C.POINTER(i32 * 4), C.POINTER(d * 4)]
         L.orc_mpc_build.argtypes = [C.POINTER(Config)] + [C.c_void_p] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mpc_build.restype = i32
@@ -131,27 +135,46 @@ def config_from_dict(cfgd):
 
 
 class OracleBatch:
-    """B independent oracle controllers (one orc_state each), stepped with OpenMP."""
+    """B independent oracle controllers (one orc_state each), stepped with OpenMP.  `gait` (optional) gives every robot
+    its own gait timing: dict of [4,B] arrays stance_duration / duty_factor / init_phase (/ init_state) -- each robot then
+    runs on its own copy of the config, like B separately constructed reference controllers would."""
 
-    def __init__(self, cfg, B, t0=0.0, nthreads=0):
+    def __init__(self, cfg, B, t0=0.0, nthreads=0, gait=None):
         self.cfg = cfg
         self.B = B
         self.states = (State * B)()
         self.nthreads = nthreads
+        self.cfgs = None
+        if gait is not None:
+            self.cfgs = (Config * B)()
+            for b in range(B):
+                C.memmove(C.byref(self.cfgs[b]), C.byref(cfg), C.sizeof(Config))
+                for l in range(4):
+                    self.cfgs[b].stance_duration[l] = float(gait["stance_duration"][l][b])
+                    self.cfgs[b].duty_factor[l] = float(gait["duty_factor"][l][b])
+                    self.cfgs[b].init_phase[l] = float(gait["init_phase"][l][b])
+                    if gait.get("init_state") is not None:
+                        self.cfgs[b].init_state[l] = int(gait["init_state"][l][b])
         for b in range(B):
-            lib().orc_reset(C.byref(cfg), C.byref(self.states[b]), t0, None)
+            lib().orc_reset(C.byref(self._cfg_of(b)), C.byref(self.states[b]), t0, None)
+
+    def _cfg_of(self, b):
+        return self.cfg if self.cfgs is None else self.cfgs[b]
 
     def reset(self, idx, t0, foot_pos=None):
         for k, b in enumerate(idx):
             fp = None if foot_pos is None else _p(np.ascontiguousarray(foot_pos[k], dtype=np.float64))
-            lib().orc_reset(C.byref(self.cfg), C.byref(self.states[int(b)]), t0, fp)
+            lib().orc_reset(C.byref(self._cfg_of(int(b))), C.byref(self.states[int(b)]), t0, fp)
 
     def step(self, t, inputs):
         """inputs: structured array of INPUT_DTYPE, shape [B]. Returns OUTPUT_DTYPE array."""
         assert inputs.dtype == INPUT_DTYPE and inputs.shape == (self.B,)
         inputs = np.ascontiguousarray(inputs)
         out = np.zeros(self.B, dtype=OUTPUT_DTYPE)
-        bad = lib().orc_step_batch(C.byref(self.cfg), C.addressof(self.states), self.B, float(t), _p(inputs), _p(out), self.nthreads)
+        if self.cfgs is not None:
+            bad = lib().orc_step_batch_cfgs(C.addressof(self.cfgs), C.addressof(self.states), self.B, float(t), _p(inputs), _p(out), self.nthreads)
+        else:
+            bad = lib().orc_step_batch(C.byref(self.cfg), C.addressof(self.states), self.B, float(t), _p(inputs), _p(out), self.nthreads)
         if bad:
             raise RuntimeError(f"oracle QP failed for {bad} robots")
         return out

@@ -19,25 +19,41 @@ STATE_FIELDS = (("rpy", 3, torch.float32), ("rpy_rate", 3, torch.float32), ("v_w
 
 class PackedState:
     """Host-resident robot state staged for ONE upload per tick: every STATE_FIELDS array is a view into a single
-    pinned [77, B] 32-bit host slab and a matching device slab (rows in STATE_FIELDS order; `contact` is the
-    int32 view of its rows), so the gym side pays one H2D copy instead of eight."""
+    pinned [82, B] 32-bit host slab and a matching device slab -- rows 0-1 are the per-robot float64 clock
+    (`t_robot`, first so that it stays 8-byte aligned for any B), then the fields in STATE_FIELDS order
+    (`contact` is the int32 view of its rows), then the offset-corrected command (`cmd`, 3 rows) -- so the gym
+    side pays one H2D copy instead of ten."""
 
     def __init__(self, batch, device, pin=None):
-        words = sum(c for _, c, _ in STATE_FIELDS)
+        words = 2 + sum(c for _, c, _ in STATE_FIELDS) + 3
         pin = torch.cuda.is_available() if pin is None else pin
         self.host_slab = torch.zeros(words, batch, dtype=torch.float32, pin_memory=pin)
         self.dev_slab = torch.zeros(words, batch, dtype=torch.float32, device=device)
         self.host, self.dev = {}, {}
-        row = 0
+        # the two clock rows hold B float64 values back to back (not one value per column)
+        self.host_clock = self.host_slab[0:2].view(-1).view(torch.float64)
+        self.dev_clock = self.dev_slab[0:2].view(-1).view(torch.float64)
+        row = 2
         for name, comps, dt in STATE_FIELDS:
             h, d = self.host_slab[row:row + comps], self.dev_slab[row:row + comps]
             self.host[name] = h if dt == torch.float32 else h.view(dt)
             self.dev[name] = d if dt == torch.float32 else d.view(dt)
             row += comps
+        self.host_cmd, self.dev_cmd = self.host_slab[row:row + 3], self.dev_slab[row:row + 3]
 
-    def upload(self):
+    def upload(self, with_clock=False, with_cmd=False):
+        """One host->device copy of the whole slab.  with_clock: the returned dict also carries the per-robot clock
+        (`t_robot`), for envs that are not in lock-step; with_cmd: and the command rows (`cmd`, robot offsets already
+        added by the caller)."""
         self.dev_slab.copy_(self.host_slab, non_blocking=True)
-        return self.dev
+        if not (with_clock or with_cmd):
+            return self.dev
+        out = dict(self.dev)
+        if with_clock:
+            out["t_robot"] = self.dev_clock
+        if with_cmd:
+            out["cmd"] = self.dev_cmd
+        return out
 
 
 def command_with_offsets(params, offsets, batch):
@@ -114,7 +130,8 @@ class BatchedMPCController:
         self._set_command_called = True
 
     def get_action(self, t, state):
-        """state: dict of component-major device tensors (STATE_FIELDS).  Returns action [B,60]
+        """state: dict of component-major device tensors (STATE_FIELDS; optional `contact_sched` int32 [4,B] and
+        `t_robot` float64 [B], the per-robot clock that replaces the scalar t).  Returns action [B,60]
         (device tensor, overwritten by the next call) -- reference mpc_controller.py:102-106."""
         sp = mpc_abi.CStatePtrs()
         for name, comps, dt in STATE_FIELDS:
@@ -126,7 +143,16 @@ class BatchedMPCController:
             if tsr.dtype != dt or tuple(tsr.shape) != (comps, self.batch) or not tsr.is_contiguous() or tsr.device != self.device:
                 raise ValueError(f"state[{name!r}] must be contiguous {dt} [{comps},{self.batch}] on {self.device}")
             setattr(sp, name, tsr.data_ptr())
-        sp.cmd = None  # use the command stored by update_controller_params
+        cmd = state.get("cmd")   # offset-corrected [3,B] command travelling with the state; None = update_controller_params' copy
+        if cmd is not None:
+            if cmd.dtype != torch.float32 or tuple(cmd.shape) != (3, self.batch) or not cmd.is_contiguous() or cmd.device != self.device:
+                raise ValueError(f"state['cmd'] must be contiguous float32 [3,{self.batch}] on {self.device}")
+            sp.cmd = cmd.data_ptr()
+        t_robot = state.get("t_robot")
+        if t_robot is not None:
+            if t_robot.dtype != torch.float64 or tuple(t_robot.shape) != (self.batch,) or not t_robot.is_contiguous() or t_robot.device != self.device:
+                raise ValueError(f"state['t_robot'] must be contiguous float64 [{self.batch}] on {self.device}")
+            sp.t_robot = t_robot.data_ptr()
         sched = state.get("contact_sched")
         if sched is not None:
             if sched.dtype != torch.int32 or tuple(sched.shape) != (4, self.batch) or not sched.is_contiguous() or sched.device != self.device:

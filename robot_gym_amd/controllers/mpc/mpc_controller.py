@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from robot_gym_amd.controllers.controller import Controller
-from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+from robot_gym_amd.controllers.mpc.batched import BatchedMPCController, PackedState
 from robot_gym_amd.controllers.mpc.kinematics import ChainKinematics, PybulletKinematics
 from robot_gym_amd.core.config import MPCConfig
 from robot_gym_amd.model.robots.robot_constants import ROBOTS
@@ -55,6 +55,9 @@ class MPCController(Controller):
         self._kinematics = PybulletKinematics(robot, self._chain)
         self._batched = BatchedMPCController(1, self._cfg, device=device, extra_outputs=True)
         self._dev = self._batched.device
+        self._state = PackedState(1, self._dev)     # one pinned slab: one H2D copy per tick instead of eight
+        self._host = {n: t.numpy() for n, t in self._state.host.items()}
+        self._act_host = torch.zeros(1, 60, dtype=torch.float32, pin_memory=True)
         self.update_controller_params((0.0, 0.0, 0.0))
 
     @property
@@ -75,19 +78,22 @@ class MPCController(Controller):
         self._batched.update_controller_params(torch.tensor([list(map(float, params))], dtype=torch.float32))
 
     def _gather_state(self):
-        rb = self._robot
-        f = lambda a, n: torch.tensor(np.asarray(a, dtype=np.float32).reshape(n, 1), device=self._dev)
-        jac = np.stack([self._kinematics.leg_jacobian(leg) for leg in range(4)])
-        return {
-            "rpy": f(rb.GetBaseRollPitchYaw(), 3), "rpy_rate": f(rb.GetBaseRollPitchYawRate(), 3),
-            "v_world": f(rb.GetBaseVelocity(), 3), "quat": f(rb.GetTrueBaseOrientation(), 4),
-            "q": f(rb.GetMotorAngles(), 12), "foot_pos": f(rb.GetFootPositionsInBaseFrame(), 12), "jac": f(jac, 36),
-            "contact": torch.tensor(np.asarray(rb.GetFootContacts(), dtype=np.int32).reshape(4, 1), device=self._dev),
-        }
+        rb, h = self._robot, self._host
+        h["rpy"][:, 0] = rb.GetBaseRollPitchYaw()
+        h["rpy_rate"][:, 0] = rb.GetBaseRollPitchYawRate()
+        h["v_world"][:, 0] = rb.GetBaseVelocity()
+        h["quat"][:, 0] = rb.GetTrueBaseOrientation()
+        h["q"][:, 0] = rb.GetMotorAngles()
+        h["foot_pos"][:, 0] = np.asarray(rb.GetFootPositionsInBaseFrame(), dtype=np.float32).reshape(12)
+        h["jac"][:, 0] = np.stack([self._kinematics.leg_jacobian(leg) for leg in range(4)]).reshape(36)
+        h["contact"][:, 0] = np.asarray(rb.GetFootContacts(), dtype=np.int32)
+        return self._state.upload()
 
     def get_action(self):
         act = self._batched.get_action(self.get_time_since_reset(), self._gather_state())
-        return act[0].cpu().numpy()
+        self._act_host.copy_(act, non_blocking=True)
+        torch.cuda.current_stream(self._dev).synchronize()
+        return self._act_host[0].numpy().copy()
 
     def reset(self):
         self._batched.reset(None, t0=self.get_time_since_reset())

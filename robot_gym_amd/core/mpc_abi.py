@@ -39,7 +39,7 @@ class CConfig(C.Structure):
 
 
 class CStatePtrs(C.Structure):
-    _fields_ = [(n, fp) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact", "cmd", "contact_sched")]
+    _fields_ = [(n, fp) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact", "cmd", "contact_sched", "t_robot")]
 
 
 class COutPtrs(C.Structure):

@@ -88,6 +88,7 @@ struct DevIn {
   const float *rpy, *rpy_rate, *v_world, *quat, *q, *foot_pos, *jac, *cmd;
   const int *contact;
   const int *contact_sched;   // [4][B] optional caller-supplied contact schedule (bit k = in contact at horizon step k)
+  const double *t_robot;      // [B] optional per-robot clock values (null: every robot at the step's scalar t)
 };
 struct DevOut {
   float *action, *grf, *tau_stance, *phase, *foot_target, *v_body;

@@ -56,15 +56,55 @@ def make_states(B, cfg: MPCConfig, seed=0, fixed_cmd=None, phase_offsets=True, c
     return state, cmd, t_off
 
 
-def gait_consistent_contacts(cfg: MPCConfig, t_rel, flip):
+def _gait_rows(cfg: MPCConfig, gait, B):
+    """[4,B] arrays of (stance_duration, duty_factor, init_phase, init_state): per robot when `gait` is given."""
+    if gait is None:
+        col = lambda v, dt: np.tile(np.asarray(v, dtype=dt).reshape(4, 1), (1, B))
+        return col(cfg.stance_duration, np.float64), col(cfg.duty_factor, np.float64), col(cfg.init_phase, np.float64), col(cfg.init_state, np.int32)
+    ist = gait.get("init_state")
+    ist = np.tile(np.asarray(cfg.init_state, dtype=np.int32).reshape(4, 1), (1, B)) if ist is None else np.asarray(ist, dtype=np.int32)
+    return (np.asarray(gait["stance_duration"], dtype=np.float64), np.asarray(gait["duty_factor"], dtype=np.float64),
+            np.asarray(gait["init_phase"], dtype=np.float64), ist)
+
+
+def gait_desired_stance(cfg: MPCConfig, t_rel, gait=None):
+    """[4,B] int32: 1 where the open-loop gait wants the leg in stance at time t_rel[B] (controller clock)."""
+    t_rel = np.asarray(t_rel, dtype=np.float64)
+    sd, du, ph0, ist = _gait_rows(cfg, gait, len(t_rel))
+    ratio = np.where(ist == 0, 1.0 - du, du)
+    full = sd / du
+    ph = np.fmod(t_rel[None, :] + ph0 * full, full) / full
+    desired = np.where(ph < ratio, ist, 1 - ist)
+    return (desired == 1).astype(np.int32)
+
+
+def gait_consistent_contacts(cfg: MPCConfig, t_rel, flip, gait=None):
     """contact[4,B] int32 = open-loop desired stance at time t_rel[B], with pre-drawn flips."""
+    return gait_desired_stance(cfg, t_rel, gait) ^ flip.astype(np.int32)
+
+
+def random_gaits(B, cfg: MPCConfig, seed=0, duty_range=(0.5, 0.8)):
+    """BASELINE config 5: every robot trots with its own duty factor ~ U(0.5, 0.8) (one value for
+    its four legs); stance duration, phase offsets and initial leg states are the robot's constants.  Returns the [4,B]
+    arrays rg_mpc_set_gait takes."""
+    rng = np.random.default_rng([seed, 0xC5])
+    duty = np.tile(rng.uniform(duty_range[0], duty_range[1], B), (4, 1))
+    sd, _, ph0, ist = _gait_rows(cfg, None, B)
+    return dict(stance_duration=sd, duty_factor=np.ascontiguousarray(duty), init_phase=ph0, init_state=ist)
+
+
+def contact_schedule(cfg: MPCConfig, t_rel, gait=None, dropout=0.1, seed=0, tick=0):
+    """Randomised contact schedule of BASELINE config 5: [4,B] int32, bit k = leg planned in contact at horizon step k
+    = the open-loop gait (per-robot timing) evaluated at t_rel + k dt_plan, with a fraction `dropout` of the planned
+    contacts removed at random (rough terrain: the foot finds no ground).  Drawn per tick from (seed, tick), on the host,
+    so the CPU oracle and the GPU path consume identical words."""
+    t_rel = np.asarray(t_rel, dtype=np.float64)
     B = len(t_rel)
-    out = np.zeros((4, B), dtype=np.int32)
-    for leg in range(4):
-        init = cfg.init_state[leg]
-        ratio = (1.0 - cfg.duty_factor[leg]) if init == 0 else cfg.duty_factor[leg]
-        full = cfg.stance_duration[leg] / cfg.duty_factor[leg]
-        ph = np.fmod(t_rel + cfg.init_phase[leg] * full, full) / full
-        desired = np.where(ph < ratio, init, 1 - init)
-        out[leg] = (desired == 1).astype(np.int32) ^ flip[leg].astype(np.int32)
-    return out
+    rng = np.random.default_rng([seed, 0x5C, tick])
+    words = np.zeros((4, B), dtype=np.int32)
+    for k in range(cfg.horizon):
+        on = gait_desired_stance(cfg, t_rel + k * cfg.dt_plan, gait)
+        if dropout > 0:
+            on = on & (rng.uniform(0, 1, (4, B)) >= dropout)
+        words |= on.astype(np.int32) << k
+    return words

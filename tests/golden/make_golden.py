@@ -6,6 +6,8 @@ reference's source travels: only seeded inputs and the outputs its code produced
 
   motor_model.npz   RobotMotorModel.convert_to_torque, HYBRID branch
                     (robot_gym/model/robots/simple_motor.py:85-148)
+  motor_model_substeps.npz  the same over the ACTION_REPEAT sub-steps of one control tick
+                    (core/simulation.py:175-179, core/sim_constants.py:7)
   force_to_torque.npz  Kinematics.MapContactForceToJointTorques with a stub pybullet
                     Jacobian (robot_gym/controllers/mpc/kinematics.py:13-53)
   adapter.json      MPCController wiring recorded through a stub `mpc_controller` package:
@@ -131,6 +133,36 @@ def gen_motor_model():
                                        simple_motor.MOTOR_CONTROL_HYBRID]))
 
 
+def gen_motor_model_substeps():
+    """The action-repeat loop of Simulation.ApplyStepAction (core/simulation.py:175-179): ONE 60-float command is
+    converted ACTION_REPEAT times (core/sim_constants.py:7), each time with that sub-step's joint angles / velocities
+    (Robot.ApplyAction -> convert_to_torque, robot.py:276-307)."""
+    from robot_gym.model.robots import simple_motor
+    from robot_gym.model.robots.ghost import motor_constants
+    from robot_gym.core import sim_constants
+    rng = np.random.default_rng(4321)
+    model = simple_motor.RobotMotorModel(num_motors=12, kp=motor_constants.MOTOR_POSITION_GAINS,
+                                         kd=motor_constants.MOTOR_VELOCITY_GAINS,
+                                         motor_control_mode=simple_motor.MOTOR_CONTROL_HYBRID)
+    n, S = 24, sim_constants.ACTION_REPEAT
+    actions = np.zeros((n, 60), dtype=np.float32)
+    q0 = rng.uniform(-1.5, 1.5, (n, 1, 12))
+    qd = rng.uniform(-8, 8, (n, S, 12)).astype(np.float32).astype(np.float64)
+    q = (q0 + np.cumsum(qd, axis=1) * sim_constants.SIMULATION_TIME_STEP).astype(np.float32).astype(np.float64)   # joints moving through the tick
+    taus = np.zeros((n, S, 12))
+    for k in range(n):
+        a = np.zeros((12, 5))
+        swing = rng.uniform(0, 1, 12) < 0.5
+        a[swing, 0] = rng.uniform(-1.5, 1.5, swing.sum())
+        a[swing, 1] = np.asarray(motor_constants.MOTOR_POSITION_GAINS)[swing]
+        a[swing, 3] = np.asarray(motor_constants.MOTOR_VELOCITY_GAINS)[swing]
+        a[~swing, 4] = rng.uniform(-40, 40, (~swing).sum())
+        actions[k] = a.reshape(60).astype(np.float32)
+        for s in range(S):   # the loop of ApplyStepAction
+            taus[k, s], _ = model.convert_to_torque(actions[k], q[k, s], qd[k, s], qd[k, s], simple_motor.MOTOR_CONTROL_HYBRID)
+    np.savez(os.path.join(OUT, "motor_model_substeps.npz"), action=actions, q=q, qd=qd, tau=taus, action_repeat=np.array(S))
+
+
 def gen_force_to_torque():
     from robot_gym.controllers.mpc.kinematics import Kinematics
     from robot_gym.model.robots.ghost import motor_constants, constants
@@ -246,6 +278,7 @@ def gen_adapter():
 
 if __name__ == "__main__":
     gen_motor_model()
+    gen_motor_model_substeps()
     gen_force_to_torque()
     gen_adapter()
     print("golden vectors written to", OUT)

@@ -22,8 +22,9 @@ def oracle_config(O, cfg: MPCConfig):
     return c
 
 
-def oracle_inputs(O, state, cmd_off, contact):
-    """component-major float32 arrays -> structured INPUT_DTYPE[B] (float64 upcast of the same values)."""
+def oracle_inputs(O, state, cmd_off, contact, sched=None):
+    """component-major float32 arrays -> structured INPUT_DTYPE[B] (float64 upcast of the same values).
+    sched: optional [4,B] int32 caller contact schedule (bit k = contact at horizon step k)."""
     B = state["rpy"].shape[1]
     inp = np.zeros(B, dtype=O.INPUT_DTYPE)
     inp["rpy"] = state["rpy"].T.astype(np.float64)
@@ -35,6 +36,9 @@ def oracle_inputs(O, state, cmd_off, contact):
     inp["jac"] = state["jac"].T.astype(np.float64).reshape(B, 4, 3, 3)
     inp["contact"] = contact.T
     inp["cmd"] = cmd_off.T.astype(np.float64)
+    if sched is not None:
+        inp["sched_valid"] = 1
+        inp["sched"] = sched.T
     return inp
 
 
@@ -44,10 +48,11 @@ def cmd_with_offsets(cfg, cmd):
     return (cmd.astype(np.float32) + off).astype(np.float32)
 
 
-def run_oracle(O, cfg, state, cmd, t_off, ticks, dt=0.01, nthreads=0, jitter=None):
+def run_oracle(O, cfg, state, cmd, t_off, ticks, dt=0.01, nthreads=0, jitter=None, gait=None, sched_fn=None):
+    """gait: per-robot gait arrays (synthetic.random_gaits); sched_fn(k, t_rel[B]) -> [4,B] int32 caller contact schedule."""
     ocfg = oracle_config(O, cfg)
     B = state["rpy"].shape[1]
-    ob = O.OracleBatch(ocfg, B, 0.0, nthreads)
+    ob = O.OracleBatch(ocfg, B, 0.0, nthreads, gait=gait)
     for b in range(B):
         ob.states[b].reset_time = -float(t_off[b])
     outs = []
@@ -55,9 +60,24 @@ def run_oracle(O, cfg, state, cmd, t_off, ticks, dt=0.01, nthreads=0, jitter=Non
     for k in range(ticks):
         t = k * dt
         st = perturb(state, k, jitter)
-        contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"])
-        outs.append(ob.step(t, oracle_inputs(O, st, coff, contact)))
+        contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"], gait)
+        sched = sched_fn(k, t + t_off) if sched_fn else None
+        outs.append(ob.step(t, oracle_inputs(O, st, coff, contact, sched)))
     return outs
+
+
+def oracle_step_each(O, ob, ts, inputs):
+    """Step robot b of an OracleBatch at ITS OWN clock value ts[b] (B separate reference controllers, each reading its own
+    simulation's clock).  Returns an OUTPUT_DTYPE array like OracleBatch.step."""
+    import ctypes as C
+    inputs = np.ascontiguousarray(inputs)
+    out = np.zeros(ob.B, dtype=O.OUTPUT_DTYPE)
+    for b in range(ob.B):
+        rc = O.lib().orc_step(C.byref(ob._cfg_of(b)), C.byref(ob.states[b]), float(ts[b]),
+                              C.cast(inputs[b:b + 1].ctypes.data, C.POINTER(O.Input)), C.cast(out[b:b + 1].ctypes.data, C.POINTER(O.Output)))
+        if rc:
+            raise RuntimeError(f"oracle QP failed for robot {b}")
+    return out
 
 
 def perturb(state, k, jitter):
@@ -71,21 +91,26 @@ def perturb(state, k, jitter):
     return st
 
 
-def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0"):
+def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0", gait=None, sched_fn=None, poison=True):
     import torch
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
     B = state["rpy"].shape[1]
     ctl = BatchedMPCController(B, cfg, device=device)
+    if gait is not None:
+        ctl.set_gait(**gait)
     ctl.reset_at(-t_off)
     ctl.update_controller_params(torch.from_numpy(cmd.T.copy()).to(device))
     outs = []
     for k in range(ticks):
         t = k * dt
         st = perturb(state, k, jitter)
-        contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"])
+        contact = synthetic.gait_consistent_contacts(cfg, t + t_off, state["_flip"], gait)
         dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).to(device) for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
         dev["contact"] = torch.from_numpy(contact).to(device)
-        ctl._handle.debug_poison_lds(ctl._stream())   # NaN bits in every CU's LDS: reads of unwritten LDS fail every time
+        if sched_fn:
+            dev["contact_sched"] = torch.from_numpy(np.ascontiguousarray(sched_fn(k, t + t_off))).to(device)
+        if poison:
+            ctl._handle.debug_poison_lds(ctl._stream())   # NaN bits in every CU's LDS: reads of unwritten LDS fail every time
         act = ctl.get_action(t, dev)
         torch.cuda.synchronize()
         o = {"action": act.cpu().numpy().copy()}
@@ -108,7 +133,11 @@ def compare_tick(og, oo, tol=1e-4):
     tau_rel = (np.abs(tau_g - tau_o).max(1) / scale)
     q_abs = np.abs(a_g[:, :, 0] - a_o[:, :, 0]).max()
     gains = np.abs(a_g[:, :, [1, 2, 3]] - a_o[:, :, [1, 2, 3]]).max()
-    res = dict(tau_rel_max=float(tau_rel.max()), tau_rel_argmax=int(tau_rel.argmax()), q_abs=float(q_abs), gains=float(gains))
+    # per-robot figure (the parity bar): max_j |dtau_j| / max(max_j |tau_j|, 1 N m).  Also reported per element:
+    # |dtau_j| / max(|tau_j|, 1 N m) -- stricter for small joint torques next to a large one
+    tau_rel_elem = np.abs(tau_g - tau_o) / np.maximum(np.abs(tau_o), 1.0)
+    res = dict(tau_rel_max=float(tau_rel.max()), tau_rel_argmax=int(tau_rel.argmax()), tau_rel_elem_max=float(tau_rel_elem.max()),
+               q_abs=float(q_abs), gains=float(gains))
     if "grf" in og:
         g_o = oo["grf"]
         gs = np.maximum(np.abs(g_o).max(1), 1.0)

@@ -10,6 +10,7 @@ import scipy.linalg
 
 from robot_gym_amd.core.config import MPCConfig
 from robot_gym_amd.controllers.mpc.kinematics import ChainKinematics
+from robot_gym_amd import synthetic
 from tests import helpers
 
 HIP = np.array([[0.22, -0.1, 0], [0.22, 0.1, 0], [-0.22, -0.1, 0], [-0.22, 0.1, 0]])
@@ -335,3 +336,41 @@ def test_contact_lookahead_extension(oracle_lib):
         assert np.abs(g[[0, 3]]).max() == 0.0 and (-g[[1, 2], 2] >= 19.0 - 1e-9).all()
         res.append(g)
     assert np.abs(res[0] - res[1]).max() > 1.0   # the plan changes when the swap is anticipated
+
+
+def test_caller_contact_schedule_and_per_robot_gaits(oracle_lib):
+    """BASELINE config 5 inputs on the oracle: (1) a caller-supplied schedule equal to the open-loop one reproduces the
+    gait-driven look-ahead exactly, bit 0 of the words is ignored, and dropping a planned contact changes the plan;
+    (2) a batch with per-robot gait rows equals separately configured single-robot controllers."""
+    O = oracle_lib
+    base = MPCConfig.for_robot("ghost", contact_lookahead=1)
+    B = 6
+    state, cmd, t_off = synthetic.make_states(B, base, seed=41)
+    gait = synthetic.random_gaits(B, base, seed=41)
+    coff = helpers.cmd_with_offsets(base, cmd)
+    contact = synthetic.gait_consistent_contacts(base, t_off, state["_flip"], gait)
+    ocfg = helpers.oracle_config(O, base)
+
+    def run(sched):
+        ob = O.OracleBatch(ocfg, B, gait=gait)
+        for b in range(B):
+            ob.states[b].reset_time = -float(t_off[b])
+        return ob.step(0.0, helpers.oracle_inputs(O, state, coff, contact, sched))
+
+    ref = run(None)
+    words = synthetic.contact_schedule(base, t_off, gait, dropout=0.0)
+    same = run(words ^ 1)                                     # bit 0 flipped: must not matter
+    np.testing.assert_array_equal(same["grf"], ref["grf"])
+    np.testing.assert_array_equal(same["action"], ref["action"])
+    dropped = run(synthetic.contact_schedule(base, t_off, gait, dropout=0.3, seed=3))
+    assert np.abs(dropped["grf"] - ref["grf"]).max() > 0.5 and dropped["kkt"].max() < 1e-6
+    # (2) per-robot rows == one config per robot
+    for b in range(B):
+        one = MPCConfig.for_robot("ghost", contact_lookahead=1, duty_factor=tuple(gait["duty_factor"][:, b]),
+                                  stance_duration=tuple(gait["stance_duration"][:, b]), init_phase=tuple(gait["init_phase"][:, b]))
+        ob1 = O.OracleBatch(helpers.oracle_config(O, one), 1)
+        ob1.states[0].reset_time = -float(t_off[b])
+        sub = {k: v[:, b:b + 1] for k, v in state.items() if k != "_flip"}
+        o1 = ob1.step(0.0, helpers.oracle_inputs(O, sub, coff[:, b:b + 1], contact[:, b:b + 1]))
+        np.testing.assert_array_equal(o1["action"][0], ref["action"][b])
+        np.testing.assert_array_equal(o1["phase"][0], ref["phase"][b])

@@ -8,16 +8,17 @@ coalesced reads by 2x -- the kernels here read 4-8 B per lane, a width the guide
 so the raw value is reported and the 2x-corrected value is given as an upper bound."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+workload_key = sys.argv[2] if len(sys.argv) > 2 else "headline"   # bench.py load_profile(): headline / config2 / config5 / h20 ...
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("rg_front_kernel", "rg_qp_fused_kernel", "rg_qp_wrench_kernel<3", "rg_qp_wrench_kernel<4", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2", "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4",
-              "rg_qp_admm_reg_kernel<1", "rg_qp_admm_reg_kernel<2", "rg_qp_admm_reg_kernel<3", "rg_qp_admm_reg_kernel<4",
-              "rg_qp_admm_kernel", "rg_reset_kernel", "rg_hybrid"):
+    for k in ("rg_front_kernel", "rg_qp_fused_retry_kernel", "rg_qp_fused_kernel", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2",
+              "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4", "rg_reset_kernel", "rg_hybrid"):
         if k in name:
             return name[name.index(k):].split("(")[0]
     return None
@@ -32,8 +33,6 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_flops"):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k is None:
-                continue
-            if int(r["Grid_Size"]) <= 8192 and ("false>" in k or "wrench" in k or "reg_kernel" in k):   # empty-bin launches of the per-bin plan
                 continue
             pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
@@ -52,7 +51,11 @@ with open(os.path.join(dst, f"{tag}_pmc_per_launch.csv"), "w") as f:
         f.write(k.replace(",", ";") + "," + ",".join("%.6g" % c.get(n, float("nan")) for n in names) + "\n")
 bl = os.path.join(src, "bench_line.json")
 meta = json.loads(open(bl).read()) if os.path.exists(bl) and os.path.getsize(bl) else {}
-json.dump({"tag": tag, "batch": (meta.get("config", {}).get("workload", "batch=4096").split("batch=")[1].split(" ")[0]), "command": "python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline (under rocprofv3)", "traffic": traffic,
+import bench
+cmd_file = os.path.join(src, "command.txt")
+json.dump({"tag": tag, "workload_key": workload_key, "source_hash": bench.source_hash(),
+           "batch": (meta.get("config", {}).get("workload", "batch=4096").split("batch=")[1].split(" ")[0]),
+           "command": (open(cmd_file).read().strip() if os.path.exists(cmd_file) else "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras") + " (under rocprofv3)", "traffic": traffic,
            "bench_line_under_profiler": meta}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc_per_launch.csv")).read())
 print(json.dumps(traffic, indent=1))
