@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
     ap.add_argument("--tol", type=float, default=None)
+    ap.add_argument("--rho2", type=float, default=None, help="second-stage ADMM rho of the contact-schedule body (0 = single stage)")
+    ap.add_argument("--switch", type=int, default=None, help="first-stage iteration count of the contact-schedule body")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region (roofline.kernel_ms is then empty)")
     ap.add_argument("--horizon", type=int, default=HORIZON, help="MPC horizon (10 = the headline workload; 20 = BASELINE configs[4] shape)")
     ap.add_argument("--lookahead", action="store_true", help="opt-in contact-schedule extension (per-step contacts from the open-loop gait)")
@@ -260,6 +262,10 @@ def main():
         over["admm_relax"] = args.relax
     if args.tol is not None:
         over["admm_tol"] = args.tol
+    if args.rho2 is not None:
+        over["admm_rho2"] = args.rho2
+    if args.switch is not None:
+        over["admm_switch"] = args.switch
     if args.lookahead:
         over["contact_lookahead"] = 1
     cfg = MPCConfig.for_robot("ghost", horizon=args.horizon, **over)
@@ -348,7 +354,7 @@ def main():
         total_units = world * B * args.steps
         value = total_units / elapsed
         names = wn[:5]
-        if "fused" in wn[1]:   # one QP launch over all stance-leg counts, then the exact re-solve launches
+        if "fused" in wn[1] or "sched" in wn[1]:   # one QP launch over all stance-leg counts, then the exact re-solve launches
             units = [B, robots[1] + robots[2] + robots[3] + robots[4], stats["retried_exact"], 0, 0]
         else:
             units = [B, robots[1], robots[2], robots[3], robots[4]]
@@ -371,7 +377,7 @@ def main():
                        "input_schedule": ("one frozen state slab (static inputs)" if ring == 1 else
                                           f"ring of {ring} state slabs resident in HBM, one per tick: v_world / rpy_rate scaled by 1 +- {args.jitter}, roll/pitch +- {0.2 * args.jitter:.3g} rad, foot positions +- {20 * args.jitter:.3g} %, measured contacts following the gait"),
                        "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value,
-                       "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}", "admm_iterations": stats,
+                       "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""), "admm_iterations": stats,
                        "warm_start": bool(cfg.warm_start), "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
                        "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective",
                        "kernel_sources": source_hash()},

@@ -108,6 +108,11 @@ typedef struct {
   int32_t warm_start;       /* opt-in (default 0): start ADMM from the robot's previous-tick (z, y) when its contact set is
                                unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve */
   int32_t reserved2;        /* must be 0 */
+  /* second ADMM stage (contact-schedule QPs): robots not converged after admm_switch iterations are re-factorised with
+   * admm_rho2 and continue from their iterate up to admm_iters.  admm_rho2 = 0 or admm_switch >= admm_iters: single stage. */
+  double admm_rho2;         /* 5e-4 */
+  int32_t admm_switch;      /* 100 */
+  int32_t reserved3;        /* must be 0 */
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per
@@ -199,8 +204,8 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
  * (ADMM iterations / active-set constraint additions) over the robots that had a QP, the number of
  * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO) and how many solves failed
  * (robots with a non-finite input or an out-of-range gait row -- counted once, given an all-zero command row and
- * left out of the QP --, active-set breakdowns, plus robots ADMM left unconverged where the plan has no exact
- * re-solve pass: RG_SOLVER_ADMM, and three / four stance legs or a contact schedule at horizon 20). */
+ * left out of the QP --, active-set breakdowns (incl. more than 160 active constraints in the wrench-space exact pass),
+ * plus, under RG_SOLVER_ADMM only, robots ADMM left unconverged). */
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);
 

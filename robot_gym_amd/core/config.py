@@ -66,6 +66,9 @@ class MPCConfig:
     contact_lookahead: int = 0   # extension: per-horizon-step contact schedule (caller-supplied, else from the open-loop gait)
     warm_start: int = 0          # opt-in: ADMM starts from the previous tick's (z, y) when the contact set is unchanged
     reserved2: int = 0           # must be 0
+    admm_rho2: float = 5e-4      # second ADMM stage of the contact-schedule QPs: robots not converged after admm_switch
+    admm_switch: int = 100       # iterations are re-factorised with admm_rho2 and continue from their iterate (0 rho2 = off)
+    reserved3: int = 0           # must be 0
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

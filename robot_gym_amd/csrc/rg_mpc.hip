@@ -26,6 +26,7 @@
 #include "rg_qp_common.inc"
 #include "rg_qp_tile_kernel.inc"
 #include "rg_qp_wrench_kernel.inc"
+#include "rg_qp_sched_kernel.inc"
 #include "rg_qp_fused_kernel.inc"
 
 // ------------------------------------------------------------------------------------
@@ -119,7 +120,8 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   // the reference cannot set the horizon at all (mpc_controller.py:47-56 passes none: upstream default 10); 10 and 20
   // (BASELINE configs[4]) are the horizons with compiled and GPU-tested solver bodies
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
-  if (c->reserved0 != 0 || c->reserved2 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0) { err = "bad second-stage ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
@@ -164,7 +166,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   for (int i = 0; i < 12; i++) d->tip[i] = c->toe_xyz[i] + c->toe_com[i];
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
-  d->rho = c->admm_rho; d->relax = c->admm_relax;
+  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->admm_switch = c->admm_switch;
   d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
@@ -193,7 +195,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,rg_qp_admm_tile_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,rg_qp_admm_tile_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -207,9 +209,10 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   // (horizon 10): front -> one exact launch per stance-leg count.
   h->fused = cfg->solver != RG_SOLVER_ACTIVE_SET;
   h->auto_retry = cfg->solver == RG_SOLVER_AUTO;
-  // exact re-solve bodies exist for every stance-leg count at horizon 10 (also under a contact schedule) and for one and
-  // two legs at horizon 20; robots outside that set which ADMM leaves unconverged are counted as failures
-  h->retry_max_nc = !h->auto_retry ? 0 : (cfg->horizon == 10 ? 4 : (cfg->contact_lookahead ? 0 : 2));
+  // exact re-solve bodies: every stance-leg count at horizon 10 (force space; under a contact schedule the absent blocks
+  // are identity rows); at horizon 20 one and two legs in force space, three and four legs and any contact schedule in
+  // wrench space (rg_qp_sched_retry_kernel).  Every robot ADMM leaves unconverged has an exact pass behind it.
+  h->retry_max_nc = h->auto_retry ? 4 : 0;
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   h->hcfg.plan = h->fused ? 1 : 0;
   if (rc) { g_create_err = h->err; delete h; return rc; }
@@ -340,11 +343,15 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (h->fused) {
     // ADMM plans: one launch over all stance-leg counts, then the (normally empty) exact re-solve lists
     // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
-    HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
+    // (a contact schedule puts every robot on the schedule body: its own launch, same work lists)
+    if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
+    else HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
     if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
+    else if (h->auto_retry && h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s));
     else if (h->auto_retry) {
-      for (int nc = h->retry_max_nc; nc >= 1; nc--) {
+      HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s));   // three and four legs (wrench space)
+      for (int nc = 2; nc >= 1; nc--) {
         hipError_t lerr;
         if (!launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2)) { h->err = "step: no exact re-solve body for this (horizon, stance legs)"; return RG_MPC_ERR_INVALID; }
         HIPCHK(h, lerr);
@@ -379,7 +386,8 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
 }
 
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
-  if (h && h->fused) return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total";
+  if (h && h->fused && h->cfg.contact_lookahead) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_sched_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
+  if (h && h->fused) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_fused_kernel,rg_qp_sched_retry_kernel + rg_qp_admm_tile_kernel,-,-,step_total";
   return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
 }
 

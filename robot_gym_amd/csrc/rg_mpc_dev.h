@@ -55,7 +55,8 @@ struct DevCfg {
   double admm_prim_tol;  // 10 * admm_abs_tol: largest |x - z| (unprojected vs projected force) accepted at convergence
   int admm_check, lookahead;
   int solver, warm;
-  int plan, pad1;        // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*)
+  int plan, admm_switch; // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*); admm_switch: first-stage iterations
+  double rho2;           // second-stage ADMM rho (0 = single stage)
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };

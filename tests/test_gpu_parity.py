@@ -64,6 +64,7 @@ def test_config5_horizon_20(oracle_lib):
     _check(gpu, orc)
     bins = np.array([g["bins"] for g in gpu])
     assert bins[:, 2].sum() > 0 and bins[:, 4].sum() > 0
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
 
 
 def test_three_leg_stance_gait(oracle_lib):
@@ -167,10 +168,29 @@ def test_collinear_feet_fall_back_to_force_space(oracle_lib):
     assert gpu[0]["solver_stats"]["retried_exact"] >= 32 and gpu[0]["solver_stats"]["failures"] == 0
 
 
+def test_horizon_20_three_and_four_legs_exact_resolve(oracle_lib):
+    """Horizon 20, walking gait (three- and four-leg stance), ADMM cut off after 40 iterations so that most robots go
+    through the exact pass: three and four legs are re-solved by the wrench-space active-set body (the 240-variable
+    force-space problem has no room for its active-set state in LDS), one and two legs by the force-space one.
+    Round 1 counted such robots as failures."""
+    cfg = MPCConfig.for_robot("ghost", horizon=20, duty_factor=(0.75,) * 4, stance_duration=(0.3,) * 4,
+                              init_phase=(0.0, 0.5, 0.25, 0.75), init_state=(1, 1, 1, 1), admm_iters=40)
+    state, cmd, t_off = synthetic.make_states(64, cfg, seed=61)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=5, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=5, jitter=0.1)
+    _check(gpu, orc)
+    bins = np.array([g["bins"] for g in gpu])
+    assert bins[:, 3].sum() > 0 and bins[:, 4].sum() > 0
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu) and gpu[-1]["solver_stats"]["retried_exact"] > 16
+    # exact results: float32 output rounding only on the re-solved robots
+    m = helpers.compare_tick(gpu[-1], orc[-1])
+    assert m["grf_rel_max"] <= 2e-5, m
+
+
 @pytest.mark.parametrize("gait", ["pace", "bound"])
 def test_unbalanced_gaits_horizon_20(oracle_lib, gait):
     """Horizon 20: robots with one or two stance legs that ADMM cannot converge are re-solved exactly too
-    (n <= 120 fits the active-set kernel's LDS); three and four legs have no exact pass at this horizon."""
+    (n <= 120 fits the force-space active-set kernel's LDS)."""
     phases = {"pace": (0.0, 0.5, 0.0, 0.5), "bound": (0.0, 0.0, 0.5, 0.5)}[gait]
     cfg = MPCConfig.for_robot("ghost", horizon=20, duty_factor=(0.5,) * 4, init_phase=phases, init_state=(1, 1, 1, 1))
     state, cmd, t_off = synthetic.make_states(48, cfg, seed=23)
