@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
     ap.add_argument("--solver", type=int, default=None, help="0 = ADMM, 1 = exact active set")
-    ap.add_argument("--warm-start", action="store_true", help="opt-in ADMM warm start from the previous tick (not the headline configuration)")
+    ap.add_argument("--cold-start", action="store_true", help="start ADMM from scratch every tick (default: warm start from the robot's previous-tick iterate)")
     ap.add_argument("--cap", type=int, default=None, help="ADMM iteration cap (keeps the convergence test)")
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
@@ -254,8 +254,8 @@ def main():
         over["solver"] = args.solver
     if args.cap is not None:
         over["admm_iters"] = args.cap
-    if args.warm_start:
-        over["warm_start"] = 1
+    if args.cold_start:
+        over["warm_start"] = 0
     if args.rho is not None:
         over["admm_rho"] = args.rho
     if args.relax is not None:
@@ -276,9 +276,9 @@ def main():
     state, cmd, t_off, slabs = make_input_ring(cfg, B, rank, device, ring, args.jitter, fixed_cmd, gait, args.random_schedule)
     gathered = torch.empty(world * B, 60, dtype=torch.float32, device=device) if (args.allgather and dist is not None) else None
 
-    def run(slab_list, steps, warmup, events):
+    def run(slab_list, steps, warmup, events, cfg_run=None):
         """`warmup` untimed then `steps` timed ticks on a fresh controller; returns (seconds, handle-side profile, stats)."""
-        ctl = BatchedMPCController(B, cfg, device=device, extra_outputs=False)
+        ctl = BatchedMPCController(B, cfg_run or cfg, device=device, extra_outputs=False)
         if gait is not None:
             ctl.set_gait(**gait)
         ctl.reset_at(-t_off)
@@ -324,7 +324,7 @@ def main():
     #    prediction from the previous tick is then perfect)
     #  - PCIe-inclusive rate: the gym side holds the robot state on the host -- pinned buffers, one upload of all inputs
     #    and one download of the action slab per tick
-    pcie_value = static_value = None
+    pcie_value = static_value = cold_value = None
     if world == 1 and dist is None and not args.no_extras:
         from robot_gym_amd.controllers.mpc.batched import PackedState
         names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
@@ -349,6 +349,11 @@ def main():
             ctl.close()
             el_s, _, _, _, ctl = run(slabs[:1], args.steps, args.warmup, False)
             static_value = B * args.steps / el_s
+        if cfg.warm_start and not args.lookahead:
+            import dataclasses
+            ctl.close()
+            el_c, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, dataclasses.replace(cfg, warm_start=0))
+            cold_value = B * args.steps / el_c
 
     if rank == 0:
         total_units = world * B * args.steps
@@ -360,7 +365,11 @@ def main():
             units = [B, robots[1], robots[2], robots[3], robots[4]]
         dom = int(np.argmax(kms[:5]))
         dur_s = kms[dom] * 1e-3
-        achieved = (ALGO_BYTES_PER_STEP * units[dom] / dur_s) / 1e9 if dur_s > 0 else 0.0
+        # algorithmic bytes of the dominant launch: the per-step I/O of DESIGN.md section 5, plus -- with the warm start -- the
+        # previous-tick ADMM iterate (z, y as float32, read and written: 16 B per QP variable, 3 * legs * horizon variables)
+        warm_on = bool(cfg.warm_start) and not args.lookahead
+        algo_bytes_launch = ALGO_BYTES_PER_STEP * units[dom] + (16 * 3 * args.horizon * sum(nc * robots[nc] for nc in range(1, 5)) if (warm_on and dom == 1) else 0)
+        achieved = (algo_bytes_launch / dur_s) / 1e9 if dur_s > 0 else 0.0
         if args.random_schedule:
             wl, wkey = f"batch={B} quadrupeds per GPU, horizon={args.horizon}, per-robot duty U(0.5,0.8), randomised contact schedule with 10% drop-outs re-drawn per tick (BASELINE configs[4])", "config5"
         elif args.fixed_cmd:
@@ -376,14 +385,14 @@ def main():
             "config": {"workload": wl,
                        "input_schedule": ("one frozen state slab (static inputs)" if ring == 1 else
                                           f"ring of {ring} state slabs resident in HBM, one per tick: v_world / rpy_rate scaled by 1 +- {args.jitter}, roll/pitch +- {0.2 * args.jitter:.3g} rad, foot positions +- {20 * args.jitter:.3g} %, measured contacts following the gait"),
-                       "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value,
+                       "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value, "cold_start_steps_per_s": cold_value,
                        "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""), "admm_iterations": stats,
-                       "warm_start": bool(cfg.warm_start), "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
+                       "warm_start": warm_on, "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
                        "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective",
                        "kernel_sources": source_hash()},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(prof, names[dom]),
-                         "units_per_launch": units[dom], "algorithmic_bytes_per_unit": ALGO_BYTES_PER_STEP,
+                         "units_per_launch": units[dom], "algorithmic_bytes_per_unit": round(algo_bytes_launch / max(units[dom], 1), 1),
                          "avg_launch_ms": kms[dom],
                          "limiter": "f64 VALU issue on a per-robot dependent chain (see issue_view), not HBM",
                          "issue_view": with_f64_rate(issue_view_from_profile(prof, names[dom]), dur_s),

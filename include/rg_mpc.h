@@ -94,7 +94,7 @@ typedef struct {
   double ik_damping;        /* lambda^2 */
   double ik_max_step;       /* rad per iteration */
   /* friction-cone ADMM */
-  int32_t admm_iters;       /* ADMM iteration cap (300); exactly this many iterations when admm_tol == 0 */
+  int32_t admm_iters;       /* ADMM iteration cap over both stages (450); exactly this many iterations when admm_tol == 0 */
   int32_t reserved0;        /* must be 0 */
   double admm_rho;          /* 1e-4 */
   double admm_relax;        /* 1.8 */
@@ -105,13 +105,14 @@ typedef struct {
                                instead of holding the current contacts: the caller's
                                rg_mpc_state_ptrs.contact_sched when given, else the open-loop desired contact state at
                                t + k*dt_plan */
-  int32_t warm_start;       /* opt-in (default 0): start ADMM from the robot's previous-tick (z, y) when its contact set is
-                               unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve */
+  int32_t warm_start;       /* 1: start ADMM from the robot's previous-tick (z, y) (stored as float32) while its contact set is
+                               unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve.
+                               0: cold start every tick.  (Not used by the contact-schedule body.) */
   int32_t reserved2;        /* must be 0 */
-  /* second ADMM stage (contact-schedule QPs): robots not converged after admm_switch iterations are re-factorised with
+  /* second ADMM stage: robots not converged after admm_switch iterations are re-factorised with
    * admm_rho2 and continue from their iterate up to admm_iters.  admm_rho2 = 0 or admm_switch >= admm_iters: single stage. */
   double admm_rho2;         /* 5e-4 */
-  int32_t admm_switch;      /* 100 */
+  int32_t admm_switch;      /* 150 */
   int32_t reserved3;        /* must be 0 */
 } rg_mpc_config;
 

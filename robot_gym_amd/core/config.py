@@ -57,17 +57,17 @@ class MPCConfig:
     solver: int = SOLVER_AUTO
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
-    admm_iters: int = 300        # ADMM cap (robots beyond it go to the exact solver under SOLVER_AUTO); exact count when admm_tol == 0
+    admm_iters: int = 450        # ADMM cap over both stages (robots beyond it go to the exact solver under SOLVER_AUTO); exact count when admm_tol == 0
     reserved0: int = 0           # must be 0 (rg_mpc_create rejects anything else)
     admm_rho: float = 1e-4
     admm_relax: float = 1.8
     admm_tol: float = 1e-6       # stop when no force moved more than admm_tol*m*g over admm_check iterations
     admm_check: int = 5          # convergence check period (5: -11 % iterations vs 10 at 6x the residual error, still 60x inside the tolerance)
     contact_lookahead: int = 0   # extension: per-horizon-step contact schedule (caller-supplied, else from the open-loop gait)
-    warm_start: int = 0          # opt-in: ADMM starts from the previous tick's (z, y) when the contact set is unchanged
+    warm_start: int = 1          # ADMM starts from the robot's previous-tick (z, y) (kept as float32) while its contact set is unchanged, like upstream's OSQP path; 0 = cold start every tick
     reserved2: int = 0           # must be 0
-    admm_rho2: float = 5e-4      # second ADMM stage of the contact-schedule QPs: robots not converged after admm_switch
-    admm_switch: int = 100       # iterations are re-factorised with admm_rho2 and continue from their iterate (0 rho2 = off)
+    admm_rho2: float = 5e-4      # second ADMM stage: robots not converged after admm_switch
+    admm_switch: int = 150       # iterations are re-factorised with admm_rho2 and continue from their iterate (0 rho2 = off)
     reserved3: int = 0           # must be 0
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0

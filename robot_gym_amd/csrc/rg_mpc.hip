@@ -18,6 +18,7 @@
 #include "../../include/rg_mpc.h"
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -348,15 +349,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     else HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
     if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
-    else if (h->auto_retry && h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s));
-    else if (h->auto_retry) {
-      HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s));   // three and four legs (wrench space)
-      for (int nc = 2; nc >= 1; nc--) {
-        hipError_t lerr;
-        if (!launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 2)) { h->err = "step: no exact re-solve body for this (horizon, stance legs)"; return RG_MPC_ERR_INVALID; }
-        HIPCHK(h, lerr);
-      }
-    }
+    else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
     return RG_MPC_OK;
   }
@@ -387,7 +380,7 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
 
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
   if (h && h->fused && h->cfg.contact_lookahead) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_sched_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
-  if (h && h->fused) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_fused_kernel,rg_qp_sched_retry_kernel + rg_qp_admm_tile_kernel,-,-,step_total";
+  if (h && h->fused) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_fused_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
   return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
 }
 

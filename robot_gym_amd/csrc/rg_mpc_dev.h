@@ -73,7 +73,7 @@ struct DevState {
   int *swing_valid;     // [B] 12-bit mask
   float *cmd;           // [3][B] rg_mpc_set_command copy
   double *rec;          // [B][RG_REC_N]
-  double *warm_z, *warm_y;  // [B][RG_WARM_N] previous-tick ADMM iterate (warm start)
+  float *warm_z, *warm_y;   // [B][RG_WARM_N] previous-tick ADMM iterate (warm start); float32: it is only a starting point
   int *warm_key;        // [B] contact mask the stored iterate belongs to (-1 = none)
   int *bins;            // [RG_NLISTS][B] work lists (see RG_NLISTS)
   int *counts;          // [RG_NCOUNTS] list lengths and failure count (see RG_NCOUNTS)
@@ -274,6 +274,12 @@ __device__ __forceinline__ double fast_rcp(double d) {
   x = fma(x, e, x);
   e = fma(-d, x, 1.0);
   return fma(x, e, x);
+}
+
+// A wave-uniform double pinned into SGPRs (two v_readfirstlane): keeps per-stage constants that come out of VALU
+// arithmetic (1 / (alpha + rho) ...) from occupying VGPRs across the solver loops.
+__device__ __forceinline__ double uniform_f64(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
 __device__ __forceinline__ void neumaier_add(double &sum, double &corr, double v) {

@@ -139,14 +139,15 @@ def test_exact_solver_on_standard_trot(oracle_lib):
 
 
 def test_warm_start_stays_within_tolerance(oracle_lib):
-    """Opt-in warm start: ADMM starts from the previous tick's iterate when the contact set is unchanged.
+    """Warm start (the default): ADMM starts from the previous tick's iterate when the contact set is unchanged.
     Same tolerance as the cold solve; fewer iterations on slowly changing states."""
     cfg = MPCConfig.for_robot("ghost", warm_start=1)
     state, cmd, t_off = synthetic.make_states(192, cfg, seed=15)
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=30, jitter=0.05)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=30, jitter=0.05)
     _check(gpu, orc)
-    cold = helpers.run_gpu(MPCConfig.for_robot("ghost"), state, cmd, t_off, ticks=30, jitter=0.05)
+    cold = helpers.run_gpu(MPCConfig.for_robot("ghost", warm_start=0), state, cmd, t_off, ticks=30, jitter=0.05)
+    _check(cold, orc)
     it_warm = np.mean([g["solver_stats"]["iters_mean"] for g in gpu[5:]])
     it_cold = np.mean([g["solver_stats"]["iters_mean"] for g in cold[5:]])
     assert it_warm < 0.8 * it_cold, (it_warm, it_cold)
@@ -169,7 +170,7 @@ def test_collinear_feet_fall_back_to_force_space(oracle_lib):
 
 
 def test_horizon_20_three_and_four_legs_exact_resolve(oracle_lib):
-    """Horizon 20, walking gait (three- and four-leg stance), ADMM cut off after 40 iterations so that most robots go
+    """Horizon 20, walking gait (three-leg stance), ADMM cut off after 40 iterations so that most robots go
     through the exact pass: three and four legs are re-solved by the wrench-space active-set body (the 240-variable
     force-space problem has no room for its active-set state in LDS), one and two legs by the force-space one.
     Round 1 counted such robots as failures."""
@@ -180,7 +181,7 @@ def test_horizon_20_three_and_four_legs_exact_resolve(oracle_lib):
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=5, jitter=0.1)
     _check(gpu, orc)
     bins = np.array([g["bins"] for g in gpu])
-    assert bins[:, 3].sum() > 0 and bins[:, 4].sum() > 0
+    assert bins[:, 3].sum() + bins[:, 4].sum() == bins.sum()     # this walk always has three (or four) legs down
     assert all(g["solver_stats"]["failures"] == 0 for g in gpu) and gpu[-1]["solver_stats"]["retried_exact"] > 16
     # exact results: float32 output rounding only on the re-solved robots
     m = helpers.compare_tick(gpu[-1], orc[-1])
