@@ -85,12 +85,18 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def profile_tag(workload_key):
+    """profiles/<tag>_* file prefix of a workload: r2 for the headline, r2_<key> for the others (tools/collect_profiles.sh)."""
+    return PROFILE_TAG if workload_key == "headline" else f"{PROFILE_TAG}_{workload_key}"
+
+
 def load_profile(batch, workload_key):
     """Committed rocprofv3 summary of this same command (profiles/<tag>_traffic.json), or None when there is none for
     this batch / workload or when it was measured on different kernel sources (then the profile-derived fields of the
     bench line are null instead of stale)."""
+    tag = profile_tag(workload_key)
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_traffic.json")))
+        prof = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json")))
     except (OSError, ValueError):
         return None
     if int(prof.get("batch", -1)) != int(batch) or prof.get("workload_key", "headline") != workload_key:
@@ -120,7 +126,7 @@ def issue_view_from_profile(prof, kernel_name):
         return None
     import csv
     base = kernel_name.split("<")[0]
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_per_launch.csv")
+    path = os.path.join(ROOT, "profiles", f"{prof['tag']}_pmc_per_launch.csv")
     if not os.path.exists(path):
         return None
     for r in csv.DictReader(open(path)):
@@ -134,7 +140,7 @@ def issue_view_from_profile(prof, kernel_name):
                     "lds_busy_frac": round(4.0 * float(r["SQ_ACTIVE_INST_LDS"]) / (cyc * 256), 3),
                     "wave_slot_occupancy": round(4.0 * float(r["SQ_WAVE_CYCLES"]) / (cyc * 2048), 3),
                     "valu_instructions_per_unit": round(float(r["SQ_INSTS_VALU"]) / float(r["SQ_WAVES"])),
-                    "source": f"profiles/{PROFILE_TAG}_pmc_per_launch.csv, kernel sources {prof.get('source_hash')} (2 waves/SIMD by register budget = 2048 wave slots)"}
+                    "source": f"profiles/{prof['tag']}_pmc_per_launch.csv, kernel sources {prof.get('source_hash')} (2 waves/SIMD by register budget = 2048 wave slots)"}
     return None
 
 
@@ -376,6 +382,8 @@ def main():
             wl, wkey = f"batch={B} quadrupeds per GPU, horizon={args.horizon}, fixed forward-velocity command (BASELINE configs[1])", "config2"
         else:
             wl, wkey = f"batch={B} quadrupeds per GPU, horizon={args.horizon}{' with gait-driven contact schedule' if args.lookahead else ''}, randomised (vx,vy,wz) commands (BASELINE configs[2])", ("headline" if args.horizon == HORIZON and not args.lookahead else f"h{args.horizon}{'la' if args.lookahead else ''}")
+            if B != BATCH_PER_GPU:
+                wkey = f"b{B}" if wkey == "headline" else f"{wkey}_b{B}"
         prof = load_profile(B, wkey)
         out = {
             "metric": f"MPC controller steps/sec (whole node), batch={B} quadrupeds, horizon={args.horizon}",
@@ -396,7 +404,7 @@ def main():
                          "avg_launch_ms": kms[dom],
                          "limiter": "f64 VALU issue on a per-robot dependent chain (see issue_view), not HBM",
                          "issue_view": with_f64_rate(issue_view_from_profile(prof, names[dom]), dur_s),
-                         "profile": (f"profiles/{PROFILE_TAG}_* (same kernel sources)" if prof else "no committed rocprof summary for these kernel sources / this workload: traffic and issue_view are null"),
+                         "profile": (f"profiles/{prof['tag']}_* (same kernel sources)" if prof else "no committed rocprof summary for these kernel sources / this workload: traffic and issue_view are null"),
                          "kernel_ms": {n: round(x, 4) for n, x in zip(names + ["step_total"], kms) if n != "-"},
                          "robots_per_stance_count": robots,
                          "note": "path is instruction-issue/latency-bound, not HBM-bound (SURVEY.md 7.3-2): see issue_view and DESIGN.md section 5"},

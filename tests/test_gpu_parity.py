@@ -230,7 +230,7 @@ def test_steady_state_filter_full_batch_1024(oracle_lib):
     _check(gpu, orc)
     last = gpu[-1]
     assert last["solver_stats"]["failures"] == 0 and last["bins"][2] > 0 and last["bins"][4] > 0
-    assert last["solver_stats"]["iters_mean"] > 40   # steady-state QPs are the hard ones
+    assert last["solver_stats"]["iters_mean"] > 25   # steady-state QPs are the hard ones (about 64 from a cold start, 40 with the warm start)
 
 
 def test_gait_phase_bit_exact_after_an_hour(oracle_lib):

@@ -9,15 +9,15 @@ so the raw value is reported and the 2x-corrected value is given as an upper bou
 import collections, csv, glob, json, os, shutil, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
-workload_key = sys.argv[2] if len(sys.argv) > 2 else "headline"   # bench.py load_profile(): headline / config2 / config5 / h20 ...
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"       # r2 (headline) or r2_<workload key>: bench.py profile_tag()
+workload_key = tag.split("_", 1)[1] if "_" in tag else "headline"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("rg_front_kernel", "rg_qp_fused_retry_kernel", "rg_qp_fused_kernel", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2",
+    for k in ("rg_front_kernel", "rg_qp_fused_retry_kernel", "rg_qp_fused_kernel", "rg_qp_sched_retry_kernel", "rg_qp_sched_kernel", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2",
               "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4", "rg_reset_kernel", "rg_hybrid"):
         if k in name:
             return name[name.index(k):].split("(")[0]
