@@ -323,11 +323,14 @@ def test_per_robot_gait_rows(oracle_lib):
     assert bins[:, 2].sum() > 0 and bins[:, 3].sum() > 0 and bins[:, 4].sum() > 0
 
 
+@pytest.mark.parametrize("cap", [450, 60])
 @pytest.mark.parametrize("horizon", [10, 20])
-def test_config5_randomised_contact_schedule(oracle_lib, horizon):
+def test_config5_randomised_contact_schedule(oracle_lib, horizon, cap):
     """BASELINE config 5 at a reduced batch: per-robot duty factor ~ U(0.5, 0.8), caller-supplied per-step contact
-    schedule = the open-loop gait at t + k dt_plan with 10 % of the planned contacts dropped at random, re-drawn every tick."""
-    cfg = MPCConfig.for_robot("ghost", horizon=horizon, contact_lookahead=1)
+    schedule = the open-loop gait at t + k dt_plan with 10 % of the planned contacts dropped at random, re-drawn every tick.
+    cap = 60 cuts ADMM short (one stage only) so that most robots take the exact pass under a real schedule: the force-space
+    active-set body with absent blocks as identity rows at horizon 10, the wrench-space one on the eliminated problem at 20."""
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon, contact_lookahead=1, admm_iters=cap)
     B = 96
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=53)
     gait = synthetic.random_gaits(B, cfg, seed=53)
@@ -336,3 +339,5 @@ def test_config5_randomised_contact_schedule(oracle_lib, horizon):
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=8, jitter=0.1, gait=gait, sched_fn=sched_fn)
     _check(gpu, orc)
     assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
+    if cap == 60:
+        assert min(g["solver_stats"]["retried_exact"] for g in gpu) > B // 4
