@@ -395,3 +395,76 @@ def test_bench_under_torchrun_world_size_1(tmp_path):
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["allgather"] is True and out["config"]["admm_iterations"]["failures"] == 0
     assert out["roofline"]["kernel"] == "rg_qp_fused_kernel" and out["roofline"]["avg_launch_ms"] > 0
+
+
+def test_set_gait_validation_and_return_to_config_gait(oracle_lib):
+    """rg_mpc_set_gait: shape errors are reported; an out-of-range row makes ITS robot a counted, contained failure every
+    tick (the others still match the oracle); passing nothing returns to the config-wide gait."""
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    cfg = MPCConfig.for_robot("ghost")
+    B = 24
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=71)
+    gait = synthetic.random_gaits(B, cfg, seed=71)
+    ctl = BatchedMPCController(B, cfg)
+    with pytest.raises(ValueError):
+        ctl.set_gait(gait["stance_duration"][:, :5], gait["duty_factor"], gait["init_phase"])
+    with pytest.raises(Exception):
+        ctl.set_gait(stance_duration=gait["stance_duration"])          # duty factor and phase must come with it
+    bad = dict(gait, duty_factor=gait["duty_factor"].copy())
+    bad["duty_factor"][:, 3] = 1.5
+    bad["duty_factor"][:, 9] = float("nan")
+    ctl.set_gait(**bad)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    dev = {n: torch.from_numpy(np.ascontiguousarray(state[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+    good = np.array([b for b in range(B) if b not in (3, 9)])
+    sub = {k: (v[:, good] if hasattr(v, "ndim") and v.ndim == 2 else v) for k, v in state.items()}
+    gsub = {k: v[:, good] for k, v in gait.items()}
+    ocfg = helpers.oracle_config(oracle_lib, cfg)
+    ob = oracle_lib.OracleBatch(ocfg, len(good), gait=gsub)
+    for i, b in enumerate(good):
+        ob.states[i].reset_time = -float(t_off[b])
+    coff = helpers.cmd_with_offsets(cfg, cmd)
+    for k in range(4):
+        contact = synthetic.gait_consistent_contacts(cfg, t_off + 0.01 * k, state["_flip"], gait)
+        dev["contact"] = torch.from_numpy(contact).cuda()
+        act = ctl.get_action(0.01 * k, dev).cpu().numpy()
+        assert ctl.solver_stats()["failures"] == 2
+        assert np.all(act[[3, 9]] == 0.0)
+        ref = ob.step(0.01 * k, helpers.oracle_inputs(oracle_lib, sub, coff[:, good], contact[:, good]))
+        m = helpers.compare_tick({"action": act[good]}, ref)
+        assert m["tau_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, (k, m)
+    # back to the config-wide gait: same as a controller that never had per-robot rows
+    ctl.set_gait()
+    ctl.reset_at(-t_off)
+    ref_ctl = BatchedMPCController(B, cfg)
+    ref_ctl.reset_at(-t_off)
+    ref_ctl.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    dev["contact"] = torch.from_numpy(synthetic.gait_consistent_contacts(cfg, t_off, state["_flip"])).cuda()
+    a1 = ctl.get_action(0.0, dev).cpu().numpy().copy()
+    a2 = ref_ctl.get_action(0.0, dev).cpu().numpy()
+    assert ctl.solver_stats()["failures"] == 0 and np.array_equal(a1, a2)
+    ctl.close(); ref_ctl.close()
+
+
+def test_vec_env_with_device_kinematics(oracle_lib):
+    """kin_mode 1 under the VecEnv: only joint angles travel (no foot positions, no Jacobians gathered on the host)."""
+    from robot_gym_amd.gym.vec_env import MPCVecEnv
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    cfg = MPCConfig.for_robot("k3lso", kin_mode=1)
+    B = 6
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=73)
+    envs = [FakeRobotGymEnv(cfg, state, b, BatchSlotController, config=cfg) for b in range(B)]
+    calls = []
+    venv = MPCVecEnv(envs, jacobian_fn=lambda env, leg: calls.append(leg))
+    venv.reset()
+    ocfg = helpers.oracle_config(oracle_lib, cfg)
+    ob = oracle_lib.OracleBatch(ocfg, B)
+    clean = {k: v for k, v in state.items() if k != "_flip"}
+    for k in range(4):
+        venv.step(cmd.T.copy())
+        ref = ob.step(0.01 * k, helpers.oracle_inputs(oracle_lib, clean, helpers.cmd_with_offsets(cfg, cmd), np.ones((4, B), dtype=np.int32)))
+        m = helpers.compare_tick({"action": np.stack([e.simulation.applied[-1] for e in envs])}, ref)
+        assert m["tau_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, (k, m)
+    assert calls == []
+    venv.close()
