@@ -341,3 +341,36 @@ def test_config5_randomised_contact_schedule(oracle_lib, horizon, cap):
     assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
     if cap == 60:
         assert min(g["solver_stats"]["retried_exact"] for g in gpu) > B // 4
+
+
+import os
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_SWEEP_SEEDS", "12"))))
+def test_randomised_configurations(oracle_lib, seed):
+    """Seeded sweep over the configuration space the C-ABI accepts: robot, horizon, kinematics mode, per-robot or config-wide
+    gait (duty 0.3..0.95, arbitrary phase offsets and initial states: flight phases, one- to four-leg stance, statically
+    unbalanced pairs), constant contacts / gait-driven schedule / caller schedule with drop-outs, warm or cold start, odd
+    batch sizes.  Everything must match the oracle with no failures."""
+    rng = np.random.default_rng(1000 + seed)
+    horizon = int(rng.choice([10, 20]))
+    mode = int(rng.integers(0, 3))            # 0 constant contacts, 1 gait-driven schedule, 2 caller schedule with drop-outs
+    duty = float(rng.uniform(0.3, 0.95))
+    over = dict(horizon=horizon, kin_mode=int(rng.integers(0, 2)), contact_lookahead=int(mode > 0), warm_start=int(rng.integers(0, 2)),
+                duty_factor=(duty,) * 4, stance_duration=(float(rng.uniform(0.15, 0.4)),) * 4,
+                init_phase=tuple(float(x) for x in rng.uniform(0, 1, 4)), init_state=tuple(int(x) for x in rng.integers(0, 2, 4)),
+                window=int(rng.integers(1, 25)))
+    cfg = MPCConfig.for_robot(str(rng.choice(["ghost", "k3lso"])), **over)
+    B = int(rng.integers(5, 70))
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=2000 + seed)
+    gait = None
+    if rng.integers(0, 2):
+        gait = synthetic.random_gaits(B, cfg, seed=seed, duty_range=(0.35, 0.9))
+        gait["init_phase"] = np.ascontiguousarray(rng.uniform(0, 1, (4, B)))
+        gait["init_state"] = np.ascontiguousarray(rng.integers(0, 2, (4, B)).astype(np.int32))
+    sched_fn = (lambda k, t_rel: synthetic.contact_schedule(cfg, t_rel, gait, dropout=0.15, seed=seed, tick=k)) if mode == 2 else None
+    ticks = 5
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=ticks, jitter=0.1, gait=gait, sched_fn=sched_fn)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=ticks, jitter=0.1, gait=gait, sched_fn=sched_fn)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu), (over, [g["solver_stats"] for g in gpu])
