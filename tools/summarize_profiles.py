@@ -24,12 +24,18 @@ def short(name):
     return None
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/, so a pass directory can hold several runs: take the latest."""
+    found = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return found[-1:]
+
+
+stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_flops"):
-    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k is None:
