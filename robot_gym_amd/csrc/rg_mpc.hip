@@ -18,7 +18,6 @@
 #include "../../include/rg_mpc.h"
 #include <math.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
