@@ -10,6 +10,8 @@ reference's source travels: only seeded inputs and the outputs its code produced
                     (core/simulation.py:175-179, core/sim_constants.py:7)
   force_to_torque.npz  Kinematics.MapContactForceToJointTorques with a stub pybullet
                     Jacobian (robot_gym/controllers/mpc/kinematics.py:13-53)
+  ik_postprocess.npz  Kinematics.ComputeMotorAnglesFromFootLocalPosition with a stub pybullet IK: joint-index
+                    selection and (angle - MOTOR_OFFSET) * MOTOR_DIRECTION (robot_gym/controllers/mpc/kinematics.py:98-133)
   adapter.json      MPCController wiring recorded through a stub `mpc_controller` package:
                     constructor kwargs (mpc_controller.py:28-66), update_controller_params
                     arithmetic for 2- and 3-tuples (:83-100), get_action call order (:102-106),
@@ -213,6 +215,57 @@ def gen_force_to_torque():
              force=np.stack([c[2] for c in cases]), tau=np.stack([c[3] for c in cases]), jv_full=np.stack([c[4] for c in cases]))
 
 
+def gen_ik_postprocess():
+    """Kinematics.ComputeMotorAnglesFromFootLocalPosition -> _EndEffectorIK (controllers/mpc/kinematics.py:98-133) with a stub
+    pybullet whose calculateInverseKinematics returns supplied joint angles: pins the joint-index selection (:95, :117-121)
+    and the joint-angle -> motor-angle arithmetic (angle - MOTOR_OFFSET) * MOTOR_DIRECTION (:127-130)."""
+    from robot_gym.controllers.mpc.kinematics import Kinematics
+    from robot_gym.model.robots.ghost import constants
+    rng = np.random.default_rng(99)
+
+    class Bullet:
+        def getBasePositionAndOrientation(self, robot_id):
+            return (0.0, 0.0, 0.0), (0.0, 0.0, 0.0, 1.0)
+
+        def multiplyTransforms(self, pa, qa, pb, qb):   # identity base pose: positions add, orientation unused by the caller
+            return tuple(np.asarray(pa, dtype=float) + np.asarray(pb, dtype=float)), tuple(qa)
+
+        def calculateInverseKinematics(self, robot_id, link_id, world_pos, solver=0):
+            self.calls.append((robot_id, link_id, tuple(float(v) for v in world_pos), solver))
+            return tuple(self.angles)
+
+    class Robot:
+        GetRobotId = 3
+        GetFootLinkIds = [10, 11, 12, 13]
+        num_motors = 12
+
+        def __init__(self, bullet, direction, offset):
+            self.pybullet_client = bullet
+            self._mc = types.SimpleNamespace(MOTOR_DIRECTION=direction, MOTOR_OFFSET=offset, NUM_MOTORS=12)
+
+        def GetConstants(self):
+            return constants
+
+        def GetMotorConstants(self):
+            return self._mc
+
+    cases = []
+    for direction, offset in ((np.ones(12), np.zeros(12)),
+                              (np.array([1, -1, 1, -1, 1, 1, 1, -1, -1, 1, 1, -1.0]), rng.uniform(-0.2, 0.2, 12))):
+        for _ in range(6):
+            bullet = Bullet()
+            bullet.calls = []
+            bullet.angles = rng.uniform(-1.5, 1.5, 12)
+            kin = Kinematics(Robot(bullet, direction, offset))
+            pos = rng.uniform(-0.3, 0.3, 3)
+            for leg in range(4):
+                idxs, motor = kin.ComputeMotorAnglesFromFootLocalPosition(leg, pos)
+                cases.append((direction, offset, bullet.angles.copy(), leg, np.asarray(idxs), np.asarray(motor), pos, bullet.calls[-1][1]))
+    np.savez(os.path.join(OUT, "ik_postprocess.npz"), direction=np.stack([c[0] for c in cases]), offset=np.stack([c[1] for c in cases]),
+             joint_angles=np.stack([c[2] for c in cases]), leg=np.array([c[3] for c in cases]), idxs=np.stack([c[4] for c in cases]),
+             motor_angles=np.stack([c[5] for c in cases]), target=np.stack([c[6] for c in cases]), link_id=np.array([c[7] for c in cases]))
+
+
 def gen_adapter():
     from robot_gym.controllers.mpc import mpc_controller as ref_mpc
     from robot_gym.model.robots import simple_motor
@@ -280,5 +333,6 @@ if __name__ == "__main__":
     gen_motor_model()
     gen_motor_model_substeps()
     gen_force_to_torque()
+    gen_ik_postprocess()
     gen_adapter()
     print("golden vectors written to", OUT)
