@@ -12,6 +12,8 @@ reference's source travels: only seeded inputs and the outputs its code produced
                     Jacobian (robot_gym/controllers/mpc/kinematics.py:13-53)
   ik_postprocess.npz  Kinematics.ComputeMotorAnglesFromFootLocalPosition with a stub pybullet IK: joint-index
                     selection and (angle - MOTOR_OFFSET) * MOTOR_DIRECTION (robot_gym/controllers/mpc/kinematics.py:98-133)
+  batch_env.json    the reference's BatchEnv (robot_gym/agents/ppo/tools/batch_env.py:18-115) driven with fake envs:
+                    returned shapes / dtypes, attribute forwarding, validation errors, close()
   adapter.json      MPCController wiring recorded through a stub `mpc_controller` package:
                     constructor kwargs (mpc_controller.py:28-66), update_controller_params
                     arithmetic for 2- and 3-tuples (:83-100), get_action call order (:102-106),
@@ -266,6 +268,75 @@ def gen_ik_postprocess():
              motor_angles=np.stack([c[5] for c in cases]), target=np.stack([c[6] for c in cases]), link_id=np.array([c[7] for c in cases]))
 
 
+def gen_batch_env():
+    """The reference's BatchEnv (agents/ppo/tools/batch_env.py:18-115, the API shape MPCVecEnv must have) driven with plain
+    fake envs: what it returns, forwards and raises.  Loaded from its file (the package __init__ pulls TensorFlow)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_batch_env", os.path.join(REF, "robot_gym", "agents", "ppo", "tools", "batch_env.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class Space:
+        def __init__(self, lo, hi):
+            self.lo, self.hi = lo, hi
+
+        def __eq__(self, other):
+            return isinstance(other, Space) and (self.lo, self.hi) == (other.lo, other.hi)
+
+        def contains(self, x):
+            return len(x) == 2 and all(self.lo <= float(v) <= self.hi for v in x)
+
+    class Env:
+        marker = "env-attribute"
+
+        def __init__(self, k, hi=1.0):
+            self.k, self.t, self.closed = k, 0, False
+            self.observation_space, self.action_space = Space(-9.0, 9.0), Space(-1.0, hi)
+
+        def step(self, action):
+            self.t += 1
+            return np.array([self.k, self.t, float(action[0])]), 0.5 * self.k, self.t >= 3, {"k": self.k}
+
+        def reset(self):
+            self.t = 0
+            return np.array([self.k, 0.0, 0.0])
+
+        def close(self):
+            self.closed = True
+
+    rec = {}
+    envs = [Env(k) for k in range(4)]
+    be = mod.BatchEnv(envs, blocking=True)
+    rec["len"] = len(be)
+    rec["getitem_is_env"] = be[2] is envs[2]
+    rec["forwarded_attribute"] = be.marker
+    rec["forwarded_space_is_env0"] = be.action_space is envs[0].action_space
+    obs = be.reset()
+    rec["reset_all"] = {"shape": list(obs.shape), "dtype": str(obs.dtype), "value": obs.tolist()}
+    actions = np.array([[0.1, 0.0], [0.2, 0.0], [0.3, 0.0], [0.4, 0.0]])
+    o, r, d, i = be.step(actions)
+    rec["step"] = {"obs": o.tolist(), "obs_dtype": str(o.dtype), "reward": r.tolist(), "reward_dtype": str(r.dtype), "done": d.tolist(),
+                   "done_dtype": str(d.dtype), "info_type": type(i).__name__, "info": list(i)}
+    sub = be.reset([1, 3])
+    rec["reset_subset"] = {"shape": list(sub.shape), "value": sub.tolist(), "env_t_after": [e.t for e in envs]}
+    bad = actions.copy()
+    bad[2, 0] = 5.0
+    try:
+        be.step(bad)
+        rec["invalid_action"] = None
+    except Exception as e:   # noqa: BLE001 -- recording what the reference raises
+        rec["invalid_action"] = {"type": type(e).__name__, "message": str(e), "env_t_after": [x.t for x in envs]}
+    try:
+        mod.BatchEnv([Env(0), Env(1, hi=2.0)], blocking=True)
+        rec["space_mismatch"] = None
+    except Exception as e:   # noqa: BLE001
+        rec["space_mismatch"] = {"type": type(e).__name__}
+    be.close()
+    rec["close_closes_envs"] = [e.closed for e in envs]
+    with open(os.path.join(OUT, "batch_env.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+
+
 def gen_adapter():
     from robot_gym.controllers.mpc import mpc_controller as ref_mpc
     from robot_gym.model.robots import simple_motor
@@ -334,5 +405,6 @@ if __name__ == "__main__":
     gen_motor_model_substeps()
     gen_force_to_torque()
     gen_ik_postprocess()
+    gen_batch_env()
     gen_adapter()
     print("golden vectors written to", OUT)

@@ -178,3 +178,71 @@ def test_vec_env_host_logic_keeps_each_envs_own_step(monkeypatch):
         vec_env.MPCVecEnv([FakeGoEnv(cfg, state, 0, _Other)], config=cfg)
     venv.close()
     assert all(e.closed for e in envs) and ctl.closed
+
+
+def test_vec_env_matches_reference_batch_env_behaviour(monkeypatch):
+    """MPCVecEnv against tests/golden/batch_env.json -- what the reference's own BatchEnv (agents/ppo/tools/batch_env.py:18-115,
+    imported by tests/golden/make_golden.py) returned, forwarded and raised when driven with the same fake envs."""
+    import json
+    import torch
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd.gym import vec_env
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    from tests.fake_envs import FakeSimulation, StubRobot
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "batch_env.json")))
+    monkeypatch.setattr(vec_env, "BatchedMPCController", _RecordingBatchedController)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    cfg = MPCConfig.for_robot("ghost")
+    state, _, _ = synthetic.make_states(4, cfg, seed=5)
+
+    class Space:   # the golden's space: two components in [lo, hi]
+        def __init__(self, lo, hi): self.lo, self.hi = lo, hi
+        def __eq__(self, other): return isinstance(other, Space) and (self.lo, self.hi) == (other.lo, other.hi)
+        def contains(self, x): return len(x) == 2 and all(self.lo <= float(v) <= self.hi for v in x)
+
+    class Env:     # the golden's env, with the controller call of RobotGymEnv.step in the middle
+        marker = "env-attribute"
+
+        def __init__(self, k, hi=1.0):
+            self.k, self.t, self.closed = k, 0, False
+            self.observation_space, self.action_space = Space(-9.0, 9.0), Space(-1.0, hi)
+            self.simulation = FakeSimulation(StubRobot(cfg, state, k), BatchSlotController, config=cfg)
+
+        def step(self, action):
+            self.simulation.controller.update_controller_params(action)
+            self.simulation.ApplyStepAction(self.simulation.controller.get_action())
+            self.t += 1
+            return np.array([self.k, self.t, float(action[0])]), 0.5 * self.k, self.t >= 3, {"k": self.k}
+
+        def reset(self):
+            self.t = 0
+            self.simulation.reset()
+            return np.array([self.k, 0.0, 0.0])
+
+        def close(self): self.closed = True
+
+    envs = [Env(k) for k in range(4)]
+    be = vec_env.MPCVecEnv(envs, config=cfg)
+    assert len(be) == gold["len"] and (be[2] is envs[2]) == gold["getitem_is_env"]
+    assert be.marker == gold["forwarded_attribute"] and (be.action_space is envs[0].action_space) == gold["forwarded_space_is_env0"]
+    obs = be.reset()
+    assert list(obs.shape) == gold["reset_all"]["shape"] and str(obs.dtype) == gold["reset_all"]["dtype"] and obs.tolist() == gold["reset_all"]["value"]
+    actions = np.array([[0.1, 0.0], [0.2, 0.0], [0.3, 0.0], [0.4, 0.0]])
+    o, r, d, i = be.step(actions)
+    g = gold["step"]
+    assert o.tolist() == g["obs"] and str(o.dtype) == g["obs_dtype"] and r.tolist() == g["reward"] and str(r.dtype) == g["reward_dtype"]
+    assert d.tolist() == g["done"] and str(d.dtype) == g["done_dtype"] and type(i).__name__ == g["info_type"] and list(i) == g["info"]
+    sub = be.reset([1, 3])
+    assert list(sub.shape) == gold["reset_subset"]["shape"] and sub.tolist() == gold["reset_subset"]["value"]
+    assert [e.t for e in envs] == gold["reset_subset"]["env_t_after"]
+    bad = actions.copy()
+    bad[2, 0] = 5.0
+    with pytest.raises(ValueError) as err:
+        be.step(bad)
+    assert type(err.value).__name__ == gold["invalid_action"]["type"] and str(err.value) == gold["invalid_action"]["message"]
+    assert [e.t for e in envs] == gold["invalid_action"]["env_t_after"]       # nothing was stepped
+    with pytest.raises(ValueError):
+        vec_env.MPCVecEnv([Env(0), Env(1, hi=2.0)], config=cfg)
+    assert gold["space_mismatch"]["type"] == "ValueError"
+    be.close()
+    assert [e.closed for e in envs] == gold["close_closes_envs"]
