@@ -14,6 +14,9 @@ reference's source travels: only seeded inputs and the outputs its code produced
                     selection and (angle - MOTOR_OFFSET) * MOTOR_DIRECTION (robot_gym/controllers/mpc/kinematics.py:98-133)
   batch_env.json    the reference's BatchEnv (robot_gym/agents/ppo/tools/batch_env.py:18-115) driven with fake envs:
                     returned shapes / dtypes, attribute forwarding, validation errors, close()
+  env_step.json     the REAL RobotGymEnv.step / GoEnv.step (robot_gym/gym/robot_gym_env.py:117-129,
+                    robot_gym/gym/envs/go_to/go_env.py:272-296) on instances made without PyBullet: call order and the
+                    commands the controller receives; and three of them stepped by this repo's MPCVecEnv
   adapter.json      MPCController wiring recorded through a stub `mpc_controller` package:
                     constructor kwargs (mpc_controller.py:28-66), update_controller_params
                     arithmetic for 2- and 3-tuples (:83-100), get_action call order (:102-106),
@@ -337,6 +340,145 @@ def gen_batch_env():
         json.dump(rec, f, indent=1, sort_keys=True)
 
 
+def _stub_env_dependencies():
+    """gym, pybullet and shapely are not installable here; the env classes only need them at import / construction time."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules.setdefault(name, m)
+        return sys.modules[name]
+
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return _Any()
+        def __getattr__(self, n): return _Any()
+
+    class _GymEnv:   # stands in for gym.Env (a plain base class)
+        pass
+
+    gym = mod("gym", Env=_GymEnv, spaces=mod("gym.spaces", Box=_Any))
+    gym.utils = mod("gym.utils", seeding=mod("gym.utils.seeding", np_random=lambda seed=None: (np.random.RandomState(seed), seed)))
+    def _pybullet_attr(n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _Any()
+
+    mod("pybullet", __getattr__=_pybullet_attr)
+    mod("pybullet_data", getDataPath=lambda: "")
+    mod("pybullet_utils", bullet_client=mod("pybullet_utils.bullet_client", BulletClient=_Any))
+    geometry = mod("shapely.geometry", LineString=_Any, MultiPoint=_Any, Point=_Any, Polygon=_Any, __path__=[])
+    geometry.polygon = mod("shapely.geometry.polygon", Polygon=_Any)
+    mod("shapely", geometry=geometry, ops=mod("shapely.ops", nearest_points=_Any()), affinity=mod("shapely.affinity", rotate=_Any(), translate=_Any()), __path__=[])
+
+
+def gen_env_step():
+    """The REAL RobotGymEnv.step (gym/robot_gym_env.py:117-129) and GoEnv.step (gym/envs/go_to/go_env.py:272-296), bound to
+    instances made without their PyBullet constructors, (1) with a recording controller: the call order and the command the
+    controller receives for raw / clipped / on-target actions; (2) three of them inside this repo's MPCVecEnv with
+    BatchSlotController as their controller and a recording stand-in for the GPU call: the reference's env code runs
+    unchanged around ONE batched controller call per tick."""
+    _stub_env_dependencies()
+    from robot_gym.gym.envs.go_to.go_env import GoEnv
+    from robot_gym.gym.robot_gym_env import RobotGymEnv
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from robot_gym_amd.gym import vec_env
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd import synthetic
+    from tests.fake_envs import StubRobot, FakeSimulation, Box
+
+    def make_env(sim, on_target=False, camera=False, log=None):
+        env = object.__new__(GoEnv)            # no __init__: that one builds a PyBullet world
+        env._simulation = sim
+        env._debug, env._policy, env._ui, env._show_plot = True, True, None, False
+        env._on_target = lambda: on_target
+        env.parse_equipment_ui_params = lambda: camera
+        env._follower = types.SimpleNamespace(cam_pos_point=types.SimpleNamespace(get_xy=lambda: (0.1, 0.2)),
+                                              cam_target_point=types.SimpleNamespace(get_xy=lambda: (0.3, 0.4)))
+        note = (lambda e: log.append(e)) if log is not None else (lambda e: None)
+        env.get_observation = lambda: (note("get_observation"), [sim.GetTimeSinceReset(), float(len(sim.applied))])[1]
+        env.reward = lambda: (note("reward"), 1.0)[1]
+        env.termination = lambda: (note("termination"), (False, {}))[1]
+        env.observation_space, env.action_space = Box([-np.inf] * 2, [np.inf] * 2), Box([-1.0, -1.0], [1.0, 1.0])
+        return env
+
+    # ---- (1) call order and commands, reference code only ----
+    log = []
+
+    class RecController:
+        MOTOR_CONTROL_MODE = 3
+        def update_controller_params(self, params): log.append(("update_controller_params", [float(x) for x in params]))
+        def get_action(self): log.append("get_action"); return np.arange(60, dtype=np.float32)
+        @staticmethod
+        def get_standing_action(): return 0., 0.
+
+    cam = types.SimpleNamespace(position=None, target=None)
+
+    class RecSim:
+        def __init__(self):
+            self.controller, self.applied = RecController(), []
+            self.robot = types.SimpleNamespace(update_equipment=lambda: log.append("update_equipment"), get_default_camera=lambda: cam)
+        def read_ui_parameters(self, ui): return False
+        def ApplyStepAction(self, a): log.append("ApplyStepAction"); self.applied.append(np.asarray(a))
+        def GetTimeSinceReset(self): return 0.01 * len(self.applied)
+
+    out = {"cases": []}
+    for name, action, kw in (("clipped", (0.9, -0.7), {}), ("inside", (0.2, 0.1), {}), ("on_target", (0.3, 0.3), {"on_target": True}),
+                             ("camera", (0.1, 0.0), {"camera": True})):
+        del log[:]
+        env = make_env(RecSim(), log=log, **kw)
+        obs, rew, done, info = env.step(action)
+        out["cases"].append({"name": name, "action": list(action), "log": [list(e) if isinstance(e, tuple) else e for e in log],
+                             "obs_type": type(obs).__name__, "camera_position": cam.position if kw.get("camera") else None})
+    del log[:]
+    plain = object.__new__(GoEnv)
+    plain._simulation = RecSim()
+    plain.get_observation, plain.reward, plain.termination = (lambda: [0.0]), (lambda: 0.0), (lambda: (False, {}))
+    RobotGymEnv.step(plain, (0.1, 0.2, 0.3), update_equip=True)
+    out["robot_gym_env_step_log"] = [list(e) if isinstance(e, tuple) else e for e in log]
+
+    # ---- (2) the same env class inside MPCVecEnv ----
+    calls = []
+
+    class RecordingBatch:
+        def __init__(self, batch, cfg, device=None, extra_outputs=False):
+            import torch
+            self.batch, self.cfg, self.device = batch, cfg, torch.device("cpu")
+        def reset_at(self, t0s, idx=None): calls.append(("reset_at", list(t0s), list(idx)))
+        def get_action(self, t, state):
+            import torch
+            calls.append(("get_action", state["cmd"].numpy().T.round(6).tolist(), state["t_robot"].numpy().tolist()))
+            act = torch.zeros(self.batch, 60)
+            act[:, 0] = torch.arange(self.batch, dtype=torch.float32)
+            act[:, 1:4] = state["cmd"].T
+            return act
+        def close(self): calls.append(("close",))
+
+    import torch
+    vec_env.BatchedMPCController = RecordingBatch
+    torch.cuda.is_available = lambda: False
+    cfg = MPCConfig.for_robot("ghost")
+    state, _, _ = synthetic.make_states(3, cfg, seed=9)
+    envs = []
+    for b, kw in enumerate(({}, {"on_target": True}, {"camera": True})):
+        sim = FakeSimulation(StubRobot(cfg, state, b), BatchSlotController, config=cfg)
+        sim.read_ui_parameters = lambda ui: False
+        sim.robot.get_default_camera = lambda: cam
+        envs.append(make_env(sim, **kw))
+    venv = vec_env.MPCVecEnv(envs, config=cfg)
+    actions = np.array([[0.9, -0.7], [0.3, 0.3], [0.1, 0.05]], dtype=np.float32)
+    ticks = []
+    for k in range(2):
+        o, r, d, i = venv.step(actions)
+        ticks.append({"obs": np.asarray(o).tolist(), "reward": np.asarray(r).tolist(), "done": np.asarray(d).tolist(),
+                      "applied_row_head": [e.simulation.applied[-1][:4].round(6).tolist() for e in envs],
+                      "equipment_updates": [e.simulation.robot.equipment_updates for e in envs]})
+    out["vec_env"] = {"actions": actions.tolist(), "ticks": ticks, "batched_calls": calls, "offsets": [cfg.vx_offset, cfg.vy_offset, cfg.wz_offset]}
+    with open(os.path.join(OUT, "env_step.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def gen_adapter():
     from robot_gym.controllers.mpc import mpc_controller as ref_mpc
     from robot_gym.model.robots import simple_motor
@@ -407,4 +549,5 @@ if __name__ == "__main__":
     gen_ik_postprocess()
     gen_batch_env()
     gen_adapter()
+    gen_env_step()
     print("golden vectors written to", OUT)
