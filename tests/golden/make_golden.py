@@ -474,6 +474,22 @@ def gen_env_step():
         ticks.append({"obs": np.asarray(o).tolist(), "reward": np.asarray(r).tolist(), "done": np.asarray(d).tolist(),
                       "applied_row_head": [e.simulation.applied[-1][:4].round(6).tolist() for e in envs],
                       "equipment_updates": [e.simulation.robot.equipment_updates for e in envs]})
+    # ---- (3) the real Simulation clock and action-repeat loop (core/simulation.py:123-127,141-142,170-179) ----
+    from robot_gym.core.simulation import Simulation
+    sim = object.__new__(Simulation)
+    applied = []
+    sim._robot = types.SimpleNamespace(ApplyAction=lambda a, mode: applied.append(mode))
+    sim._pybullet_client = types.SimpleNamespace(stepSimulation=lambda: None)
+    sim.controller = types.SimpleNamespace(MOTOR_CONTROL_MODE=3, reset=lambda: applied.append("controller.reset"))
+    sim.reset()
+    clock = []
+    for _ in range(12):
+        sim.ApplyStepAction(np.zeros(60))
+        clock.append(sim.GetTimeSinceReset())
+    n_apply = len([a for a in applied if a == 3])
+    sim.reset()
+    out["simulation_clock"] = {"after_each_tick_hex": [float(c).hex() for c in clock], "sim_steps_per_tick": n_apply // 12,
+                               "reset_calls_controller_reset": applied.count("controller.reset"), "after_reset": sim.GetTimeSinceReset()}
     out["vec_env"] = {"actions": actions.tolist(), "ticks": ticks, "batched_calls": calls, "offsets": [cfg.vx_offset, cfg.vy_offset, cfg.wz_offset]}
     with open(os.path.join(OUT, "env_step.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
