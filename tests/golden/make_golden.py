@@ -480,7 +480,7 @@ def gen_env_step():
     applied = []
     sim._robot = types.SimpleNamespace(ApplyAction=lambda a, mode: applied.append(mode))
     sim._pybullet_client = types.SimpleNamespace(stepSimulation=lambda: None)
-    sim.controller = types.SimpleNamespace(MOTOR_CONTROL_MODE=3, reset=lambda: applied.append("controller.reset"))
+    sim._controller_obj = types.SimpleNamespace(MOTOR_CONTROL_MODE=3, reset=lambda: applied.append("controller.reset"))
     sim.reset()
     clock = []
     for _ in range(12):

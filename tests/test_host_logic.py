@@ -297,7 +297,7 @@ def test_reference_env_step_fixture_and_fake_env_fidelity(monkeypatch):
 def test_fake_simulation_clock_is_the_reference_clock():
     """The reference's Simulation.GetTimeSinceReset / ApplyStepAction / reset (core/simulation.py:123-127,141-142,175-179), run
     for real by make_golden.py: step_counter * 0.001 after 10 simulation steps per tick -- bit for bit what the fake simulation
-    of the tests (and therefore the per-robot clocks MPCVecEnv hands the controller) produces.  Note 70 * 0.001 != 7 * 0.01."""
+    of the tests (and therefore the per-robot clocks MPCVecEnv hands the controller) produces."""
     import json
     from tests.fake_envs import FakeSimulation
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "env_step.json")))["simulation_clock"]
@@ -313,4 +313,3 @@ def test_fake_simulation_clock_is_the_reference_clock():
         sim.ApplyStepAction(np.zeros(60))
         got.append(float(sim.GetTimeSinceReset()).hex())
     assert got == gold["after_each_tick_hex"]
-    assert float.fromhex(got[6]) != 7 * 0.01          # why the envs' own clock values travel, not tick * 0.01
