@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--rho", type=float, default=None)
     ap.add_argument("--relax", type=float, default=None)
     ap.add_argument("--tol", type=float, default=None)
+    ap.add_argument("--extrap", type=float, default=None, help="geometric-extrapolation convergence guard (admm_extrap; 0 = off)")
     ap.add_argument("--check", type=int, default=None, help="convergence vote period")
     ap.add_argument("--rho2", type=float, default=None, help="second-stage ADMM rho of the contact-schedule body (0 = single stage)")
     ap.add_argument("--switch", type=int, default=None, help="first-stage iteration count of the contact-schedule body")
@@ -269,6 +270,8 @@ def main():
         over["admm_relax"] = args.relax
     if args.tol is not None:
         over["admm_tol"] = args.tol
+    if args.extrap is not None:
+        over["admm_extrap"] = args.extrap
     if args.check is not None:
         over["admm_check"] = args.check
     if args.rho2 is not None:

@@ -114,6 +114,9 @@ typedef struct {
   double admm_rho2;         /* 5e-4 */
   int32_t admm_switch;      /* 150 */
   int32_t reserved3;        /* must be 0 */
+  double admm_extrap;       /* 5: third convergence condition -- the distance still to go estimated from the shrink rate of
+                               the movement per vote window, m r / (1 - r), must be below admm_extrap * admm_tol * m * g
+                               (stops crawling robots from passing the "stopped moving" test early); 0 = off */
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per

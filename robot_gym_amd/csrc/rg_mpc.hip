@@ -121,7 +121,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   // (BASELINE configs[4]) are the horizons with compiled and GPU-tested solver bodies
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
-  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0) { err = "bad second-stage ADMM parameters"; return RG_MPC_ERR_INVALID; }
+  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
@@ -166,7 +166,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   for (int i = 0; i < 12; i++) d->tip[i] = c->toe_xyz[i] + c->toe_com[i];
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
-  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->admm_switch = c->admm_switch;
+  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->admm_switch = c->admm_switch; d->admm_extrap = c->admm_extrap > 0.0 ? c->admm_extrap : INFINITY;
   d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)

@@ -4,10 +4,15 @@ from oracle import oracle as O
 from robot_gym_amd.core.config import MPCConfig
 from robot_gym_amd import synthetic
 from tests import helpers
-for name, kw, B, ticks, seed in (("trot", {}, 2048, 30, 0), ("walk", dict(duty_factor=(0.75,)*4, init_phase=(0.0,0.5,0.25,0.75), init_state=(1,1,1,1)), 512, 20, 7)):
-    cfg = MPCConfig.for_robot("ghost", **kw)
+import os
+TOL = float(os.environ.get("TOL", "1e-6"))
+for name, kw, B, ticks, seed in (("trot", {}, 4096, 50, 0), ("trot-k3lso-kin1", dict(kin_mode=1), 2048, 40, 3), ("walk", dict(duty_factor=(0.75,)*4, init_phase=(0.0,0.5,0.25,0.75), init_state=(1,1,1,1)), 1024, 30, 7)):
+    kw = dict(kw, admm_tol=TOL, admm_extrap=float(os.environ.get("EXTRAP", "2")))
+    cfg = MPCConfig.for_robot("k3lso" if "k3lso" in name else "ghost", **kw)
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed)
     orc = helpers.run_oracle(O, cfg, state, cmd, t_off, ticks=ticks, jitter=0.1)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=ticks, jitter=0.1, poison=False)
     w = [helpers.compare_tick(g, o) for g, o in zip(gpu, orc)]
+    allerr = np.concatenate([np.abs(g["action"].reshape(B,12,5)[:,:,4].astype(np.float64) - o["action"].reshape(B,12,5)[:,:,4].astype(np.float64)).max(1) / np.maximum(np.abs(o["action"].reshape(B,12,5)[:,:,4]).max(1), 1.0) for g, o in zip(gpu, orc)])
+    print("   robot-ticks", allerr.size, "p50 %.1e p99 %.1e p99.9 %.1e max %.1e" % tuple(np.percentile(allerr, [50, 99, 99.9, 100])))
     print(name, "check", cfg.admm_check, "tau_rel_max", max(m["tau_rel_max"] for m in w), "elem", max(m["tau_rel_elem_max"] for m in w), "grf", max(m["grf_rel_max"] for m in w), "iters", gpu[-1]["solver_stats"]["iters_mean"])
