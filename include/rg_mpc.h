@@ -113,7 +113,11 @@ typedef struct {
    * admm_rho2 and continue from their iterate up to admm_iters.  admm_rho2 = 0 or admm_switch >= admm_iters: single stage. */
   double admm_rho2;         /* 5e-4 */
   int32_t admm_switch;      /* 150 */
-  int32_t reserved3;        /* must be 0 */
+  int32_t admm_accel;       /* 40: from this iteration on, a convergence vote may extrapolate the iterate (z, y) along its
+                               dominant mode (Aitken step: consecutive vote-to-vote displacements parallel, shrinking by a
+                               steady ratio r -> jump by r / (1 - r) of the last displacement).  Halves the iteration count
+                               of the few crawling robots per tick that bound the launch; the convergence tests are
+                               unchanged.  0 = off */
   double admm_extrap;       /* 5: third convergence condition -- the distance still to go estimated from the shrink rate of
                                the movement per vote window, m r / (1 - r), must be below admm_extrap * admm_tol * m * g
                                (stops crawling robots from passing the "stopped moving" test early); 0 = off */

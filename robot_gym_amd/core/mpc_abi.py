@@ -35,7 +35,7 @@ class CConfig(C.Structure):
         ("toe_com", d * 12), ("base_com", d * 3), ("ik_iters", i32), ("solver", i32), ("ik_damping", d),
         ("ik_max_step", d), ("admm_iters", i32), ("reserved0", i32), ("admm_rho", d), ("admm_relax", d),
         ("admm_tol", d), ("admm_check", i32), ("contact_lookahead", i32), ("warm_start", i32), ("reserved2", i32),
-        ("admm_rho2", d), ("admm_switch", i32), ("reserved3", i32), ("admm_extrap", d),
+        ("admm_rho2", d), ("admm_switch", i32), ("admm_accel", i32), ("admm_extrap", d),
     ]
 
 

@@ -34,7 +34,8 @@
 #define REC_SCHED 88    // 4 doubles: per leg, bit k = in contact at horizon step k (look-ahead extension)
 
 struct DevCfg {
-  int H, window, kin_mode, ik_iters, admm_iters, pad0;
+  int H, window, kin_mode, ik_iters, admm_iters;
+  int accel_from;        // first ADMM iteration at which a vote may extrapolate the iterate along its dominant mode (0 = never)
   double dt, mass, inv_mass, body_height, alpha, mu, fz_min, fz_max, g;
   double Iinv[9];
   double w[13];
@@ -263,6 +264,26 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   v = fmin(v, dpp_f64<0x140>(v));            // 15 - i : 16 lanes
   v = fmin(v, dpp_f64_masked<0x142, 0xA>(v)); // row_bcast15 into rows 1, 3
   v = fmin(v, dpp_f64_masked<0x143, 0xC>(v)); // row_bcast31 into rows 2, 3
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_or_zero(double x) {   // lanes outside ROW_MASK get 0
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave (same DPP ladder as wave_min_f64).  Every lane gets the result.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  v += dpp_f64_or_zero<0x142, 0xA>(v);   // rows 1, 3 += lane 15 of the row before
+  v += dpp_f64_or_zero<0x143, 0xC>(v);   // rows 2, 3 += lane 31
   int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
