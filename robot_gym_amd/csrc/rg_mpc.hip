@@ -370,7 +370,8 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
   HIPCHK(h, hipSetDevice(h->device));
   while ((int)h->ev.size() < max_steps * RG_PROF_EV) {
     hipEvent_t e;
-    HIPCHK(h, hipEventCreate(&e));
+    // timing-only events: no system-scope fence when they are recorded (a default event costs ~1.3 us more of stream time per record)
+    HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
     h->ev.push_back(e);
   }
   h->prof_max = max_steps; h->prof_n = 0; h->tick = 0;
