@@ -75,8 +75,9 @@ def admm(P, q, z0, y0, mu, lo, hi, tol, rho1=1e-4, rho2=5e-4, switch=150, cap=45
     zc, yc = z.copy(), y.copy()
     dz0 = np.full((N, n), np.inf)
     dy0 = np.zeros((N, n))
-    hist = np.ones(N, int)
-    gmax = np.zeros(N)
+    hist = np.zeros(N, int)      # valid windows of displacement history before the current one
+    gmax = np.zeros(N)           # largest extrapolation gain of the stage
+    rfac = np.zeros(N)           # remaining_distance_factor of the previous vote
     for it in range(1, cap + 1):
         act = ~done
         x = np.einsum('nij,nj->ni', G, rho[:, None] * (z - y) - q)
@@ -90,25 +91,31 @@ def admm(P, q, z0, y0, mu, lo, hi, tol, rho1=1e-4, rho2=5e-4, switch=150, cap=45
             m, mp = np.abs(dz), np.abs(dz0)
             with np.errstate(invalid="ignore", divide="ignore"):
                 est = np.where((mp > m) & np.isfinite(mp), m * m / (mp - m), 0.0)
-            est = np.maximum(est, m * gmax[:, None])
+            jumped = gmax > 0           # extrapolated in this stage: known-rate / whole-iterate-rate estimates, two quiet windows
+            est = np.maximum(est, m * np.where(jumped, np.maximum(gmax, rfac), 0.0)[:, None])
             t = (tol * np.where(stage == 1, rho1 / rho2, 1.0))[:, None]
-            moving = ((m > t) | (est > extrap * t) | (np.abs(x - z) > 10 * t)).any(1) | (hist == 0)
+            with np.errstate(invalid="ignore"):
+                loud_before = jumped[:, None] & (mp > 4 * t)
+            moving = ((m > t) | (est > extrap * t) | (np.abs(x - z) > 10 * t) | loud_before).any(1) | (jumped & (hist <= 0))
             done |= act & ~moving
-            ok0 = np.isfinite(dz0).all(1)
-            dz0f = np.where(np.isfinite(dz0), dz0, 0.0)
+            dz0f = np.where(np.isfinite(dz0) & (hist >= 1)[:, None], dz0, 0.0)
+            dy0f = np.where((hist >= 1)[:, None], dy0, 0.0)
             d11 = (dz * dz).sum(1) + (dy * dy).sum(1)
-            d00 = (dz0f * dz0f).sum(1) + (dy0 * dy0).sum(1)
-            d10 = (dz * dz0f).sum(1) + (dy * dy0).sum(1)
-            jump = (~done) & ok0 & (hist >= 2) & (accel_from > 0) & (it >= accel_from) & (d10 > 0) & (d10 * d10 > 0.9 * d11 * d00) & (d10 > 0.5 * d00) & (d10 < 0.98 * d00)
+            d00 = (dz0f * dz0f).sum(1) + (dy0f * dy0f).sum(1)
+            d10 = (dz * dz0f).sum(1) + (dy * dy0f).sum(1)
+            rate_now = (~done) & (hist >= 1) & (accel_from > 0) & (it >= accel_from)
+            jump = rate_now & (d10 > 0) & (d10 * d10 > 0.9 * d11 * d00) & (d10 > 0.5 * d00) & (d10 < 0.98 * d00)
             with np.errstate(invalid="ignore", divide="ignore"):
                 g = np.where(jump, d10 / (d00 - d10), 0.0)
+                r = np.minimum(d10 / d00, 0.999)
+                rf = np.where((d10 > 0) & (d10 * d10 > 0.5 * d11 * d00), r / (1 - r), 0.0)
+            rfac = np.where(rate_now, np.where(jump, 0.0, rf), rfac)
             z = np.where(jump[:, None], z + g[:, None] * dz, z)
             y = np.where(jump[:, None], y + g[:, None] * dy, y)
             gmax = np.maximum(gmax, g)
             jumps += jump
             hist = np.where(jump, 0, hist + 1)
-            dz0 = np.where(jump[:, None], np.inf, dz)
-            dy0 = dy
+            dz0, dy0 = dz, dy
             zc, yc = z.copy(), y.copy()
         if restart_at and it == restart_at:      # remedy tried and rejected: an unconverged warm start restarts cold
             rs = ~done
@@ -126,8 +133,9 @@ def admm(P, q, z0, y0, mu, lo, hi, tol, rho1=1e-4, rho2=5e-4, switch=150, cap=45
                 zc[sw], yc[sw] = z[sw], y[sw]
                 dz0[sw] = np.inf
                 dy0[sw] = 0
-                hist[sw] = 1
+                hist[sw] = 0
                 gmax[sw] = 0
+                rfac[sw] = 0
         if done.all():
             break
     return z, np.where((stage == 1)[:, None], y * rho2 / rho1, y), iters, done, jumps

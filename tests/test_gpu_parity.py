@@ -347,12 +347,11 @@ import json
 import os
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_SWEEP_SEEDS", "12"))))
-def test_randomised_configurations(oracle_lib, seed):
-    """Seeded sweep over the configuration space the C-ABI accepts: robot, horizon, kinematics mode, per-robot or config-wide
-    gait (duty 0.3..0.95, arbitrary phase offsets and initial states: flight phases, one- to four-leg stance, statically
-    unbalanced pairs), constant contacts / gait-driven schedule / caller schedule with drop-outs, warm or cold start, odd
-    batch sizes.  Everything must match the oracle with no failures."""
+def _sweep_case(seed):
+    """One point of the configuration space the C-ABI accepts, drawn from `seed`: robot, horizon, kinematics mode, per-robot
+    or config-wide gait (duty 0.3..0.95, arbitrary phase offsets and initial states: flight phases, one- to four-leg stance,
+    statically unbalanced pairs), constant contacts / gait-driven schedule / caller schedule with drop-outs, warm or cold
+    start, odd batch sizes."""
     rng = np.random.default_rng(1000 + seed)
     horizon = int(rng.choice([10, 20]))
     mode = int(rng.integers(0, 3))            # 0 constant contacts, 1 gait-driven schedule, 2 caller schedule with drop-outs
@@ -371,13 +370,41 @@ def test_randomised_configurations(oracle_lib, seed):
         gait["init_phase"] = np.ascontiguousarray(rng.uniform(0, 1, (4, B)))
         gait["init_state"] = np.ascontiguousarray(rng.integers(0, 2, (4, B)).astype(np.int32))
     sched_fn = (lambda k, t_rel: synthetic.contact_schedule(cfg, t_rel, gait, dropout=0.15, seed=seed, tick=k)) if mode == 2 else None
-    ticks = 5
-    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=ticks, jitter=0.1, gait=gait, sched_fn=sched_fn)
-    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=ticks, jitter=0.1, gait=gait, sched_fn=sched_fn)
+    return cfg, B, over, dict(state=state, cmd=cmd, t_off=t_off, ticks=5, jitter=0.1, gait=gait, sched_fn=sched_fn)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_SWEEP_SEEDS", "12"))))
+def test_randomised_configurations(oracle_lib, seed):
+    """Seeded sweep over the configuration space (see _sweep_case).  Everything must match the oracle with no failures."""
+    cfg, B, over, kw = _sweep_case(seed)
+    orc = helpers.run_oracle(oracle_lib, cfg, **kw)
+    gpu = helpers.run_gpu(cfg, **kw)
     if os.environ.get("RG_SWEEP_VERBOSE"):
         print(seed, cfg.robot, B, over, [(round(helpers.compare_tick(g, o)["tau_rel_max"], 7), g["solver_stats"]["iters_max"], g["solver_stats"]["retried_exact"]) for g, o in zip(gpu, orc)])
     _check(gpu, orc)
     assert all(g["solver_stats"]["failures"] == 0 for g in gpu), (over, [g["solver_stats"] for g in gpu])
+
+
+def test_launch_order_independence(oracle_lib):
+    """The same configuration gives the same commands (to 1e-5, a tenth of the tolerance) whatever ran on the device before it.  Found necessary
+    when a build of the horizon-20 fused launch was right on a fresh device and wrong (forces 10-30 % off for its three-leg
+    robots, not NaN) once any other QP kernel had run in the process: wave registers are not cleared between kernels, so a
+    value read before it is written shows up exactly like this.  Sequence: horizon 20 constant contacts (fused launch,
+    256 lanes), horizon 10 gait schedule (schedule kernel), horizon 20 caller schedule, horizon 10 constant contacts, then
+    all of them again in another order."""
+    cases = {s: _sweep_case(s) for s in (9, 0, 1, 3, 12, 2)}     # (H20 fused) (H10 sched) (H20 sched) (H10 fused) (H20 fused) (H20 sched, warm)
+    first = {}
+    for order in ((9, 0, 1, 3, 12, 2), (2, 12, 9, 3, 1, 0, 9)):
+        for s in order:
+            cfg, B, over, kw = cases[s]
+            gpu = helpers.run_gpu(cfg, **kw)
+            acts = np.stack([g["action"] for g in gpu])
+            if s in first:   # (not bit for bit: which wave wins a tie in the exact solver's ratio test may differ, a few ulp of float32)
+                d = np.abs(acts.astype(np.float64) - first[s]).max(axis=(0, 2)) / np.maximum(np.abs(first[s]).max(axis=(0, 2)), 1.0)
+                assert d.max() <= 1e-5, (s, d.max())
+            else:
+                first[s] = acts
+                _check(gpu, helpers.run_oracle(oracle_lib, cfg, **kw))
 
 
 def test_long_run_error_tail_k3lso_device_kinematics(oracle_lib):
