@@ -386,12 +386,14 @@ def test_randomised_configurations(oracle_lib, seed):
 
 
 def test_launch_order_independence(oracle_lib):
-    """The same configuration gives the same commands (to 1e-5, a tenth of the tolerance) whatever ran on the device before it.  Found necessary
-    when a build of the horizon-20 fused launch was right on a fresh device and wrong (forces 10-30 % off for its three-leg
-    robots, not NaN) once any other QP kernel had run in the process: wave registers are not cleared between kernels, so a
-    value read before it is written shows up exactly like this.  Sequence: horizon 20 constant contacts (fused launch,
-    256 lanes), horizon 10 gait schedule (schedule kernel), horizon 20 caller schedule, horizon 10 constant contacts, then
-    all of them again in another order."""
+    """The same configuration gives the same commands (to 1e-5, a tenth of the tolerance) whatever ran on the device before it.
+    Found necessary when a build of the horizon-20 fused launch was right on a fresh device and wrong (forces 10-30 % off
+    for its three-leg robots, not NaN, every counter clean) once any other QP kernel had run in the process.  Root cause:
+    __syncthreads_or gave one wave of a 256-lane workgroup a different vote result than the others when the launch's
+    timing shifted (cold instruction cache); that wave left the ADMM loop at its first vote.  workgroup_any
+    (rg_qp_common.inc) no longer uses it; this test fails on the old one.  Sequence: horizon 20 constant contacts (fused
+    launch, 256 lanes), horizon 10 gait schedule (schedule kernel), horizon 20 caller schedule, horizon 10 constant
+    contacts, then all of them again in another order."""
     cases = {s: _sweep_case(s) for s in (9, 0, 1, 3, 12, 2)}     # (H20 fused) (H10 sched) (H20 sched) (H10 fused) (H20 fused) (H20 sched, warm)
     first = {}
     for order in ((9, 0, 1, 3, 12, 2), (2, 12, 9, 3, 1, 0, 9)):
