@@ -113,7 +113,7 @@ typedef struct {
    * admm_rho2 and continue from their iterate up to admm_iters.  admm_rho2 = 0 or admm_switch >= admm_iters: single stage. */
   double admm_rho2;         /* 5e-4 */
   int32_t admm_switch;      /* 150 */
-  int32_t admm_accel;       /* 40: from this iteration on, a convergence vote may extrapolate the iterate (z, y) along its
+  int32_t admm_accel;       /* 80: from this iteration on, a convergence vote may extrapolate the iterate (z, y) along its
                                dominant mode (Aitken step: consecutive vote-to-vote displacements parallel, shrinking by a
                                steady ratio r -> jump by r / (1 - r) of the last displacement).  Cuts the few crawling robots
                                per tick that bound the launch by a third to a half; a robot that has jumped has to pass

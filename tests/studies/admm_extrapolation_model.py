@@ -58,7 +58,7 @@ def proj_pyramid(w, mu, lo, hi):
     return out
 
 
-def admm(P, q, z0, y0, mu, lo, hi, tol, rho1=1e-4, rho2=5e-4, switch=150, cap=450, chk=5, relax=1.8, extrap=5.0, accel_from=40,
+def admm(P, q, z0, y0, mu, lo, hi, tol, rho1=1e-4, rho2=5e-4, switch=150, cap=450, chk=5, relax=1.8, extrap=5.0, accel_from=80,
          restart_at=0):
     """The kernels' ADMM, batched: two stages, votes every `chk` iterations (movement, primal residual, geometric distance
     estimate incl. the known rate of a jumped mode), extrapolation from iteration `accel_from` (0 = off).
@@ -154,10 +154,10 @@ if __name__ == "__main__":
     n = 60
     cold_z = np.zeros((B, n))
     cold_z[:, 2::3] = lo
-    warm = {a: (cold_z.copy(), np.zeros((B, n))) for a in (0, 40)}
+    warm = {a: (cold_z.copy(), np.zeros((B, n))) for a in (0, 80)}
     for j in range(ticks):
         P, q = build_trot_qps(O, cfg, ocfg, B, j)
-        for a in (0, 40):
+        for a in (0, 80):
             z, y, it, done, jumps = admm(P, q, *warm[a], mu, lo, hi, tol, accel_from=a)
             warm[a] = (z.astype(np.float32).astype(float), y.astype(np.float32).astype(float))
             print(f"tick {j} accel {a:2d}: mean {it.mean():5.1f}  top {np.sort(it)[::-1][:6]}  unconverged {int((~done).sum())}  jumps/robot {jumps.mean():.3f}")

@@ -398,12 +398,12 @@ def test_admm_extrapolation_model_reaches_the_exact_optimum(oracle_lib):
     P, q = P[idx], q[idx]
     z0 = np.zeros_like(q)
     z0[:, 2::3] = lo
-    runs = {a: model.admm(P, q, z0, np.zeros_like(q), mu, lo, hi, tol, accel_from=a) for a in (0, 40)}
+    runs = {a: model.admm(P, q, z0, np.zeros_like(q), mu, lo, hi, tol, accel_from=a) for a in (0, 80)}
     for a, (z, y, it, done, jumps) in runs.items():
         assert done.all()
         for k in range(len(idx)):
             u, _, _ = O.qp_solve(P[k], q[k], mu, lo, hi)
             assert np.abs(z[k, :6] - u[:6]).max() <= 2e-5 * max(1.0, np.abs(u[:6]).max()), (a, k)
-    it0, it1 = runs[0][2], runs[40][2]
+    it0, it1 = runs[0][2], runs[80][2]
     assert (it0[:3] >= 180).all() and (it1[:3] <= 0.67 * it0[:3]).all(), (it0[:3], it1[:3])
-    assert (it1 <= it0 + 10).all() and runs[40][4][:3].min() >= 1 and runs[0][4].sum() == 0
+    assert (it1 <= it0 + 10).all() and runs[80][4][:3].min() >= 1 and runs[0][4].sum() == 0
