@@ -6,7 +6,6 @@ device buffers and the current stream; all arithmetic happens in librg_mpc.so.
 """
 import ctypes as C
 
-import numpy as np
 import torch
 
 from robot_gym_amd.core import mpc_abi

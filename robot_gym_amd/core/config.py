@@ -7,10 +7,9 @@ override (horizon, plan dt, QP weights, friction, alpha ...).  Those upstream de
 NOT in the reference tree; they are restated from the published library and are therefore
 ordinary, documented configuration here.
 """
-from dataclasses import dataclass, field, asdict
+from dataclasses import dataclass, asdict
 from typing import Tuple
 
-import numpy as np
 
 from robot_gym_amd.model.robots.robot_constants import ROBOTS, RobotConstants
 

@@ -11,7 +11,6 @@ import os
 from dataclasses import dataclass, field
 from typing import Tuple
 
-import numpy as np
 
 from robot_gym_amd.controllers.mpc.gait import LegState
 

@@ -8,7 +8,6 @@ import os
 import random
 import sys
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
