@@ -201,8 +201,10 @@ __device__ inline void leg_ik(const DevCfg *c, int leg, const double target[3], 
       for (int j = 0; j < 3; j++) J[3 * i + j] *= c->mdir[3 * leg + j];
 #pragma unroll
     for (int i = 0; i < 3; i++) e[i] = target[i] - p[i];
-    // converged to 1e-12 m: the remaining fixed-count iterations of the CPU arithmetic move q by < 1e-11 rad
-    if (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] < 1e-24) break;
+    // converged to 1e-9 m: the remaining fixed-count iterations of the CPU arithmetic move q by < 1e-8 rad, a tenth of
+    // the float32 resolution of the joint angle that goes into the command row (Newton is quadratic here: waiting for
+    // 1e-12 m cost one more forward-kinematics pass, 0.5 us of the front kernel)
+    if (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] < 1e-18) break;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
