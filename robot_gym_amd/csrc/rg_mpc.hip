@@ -134,7 +134,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
     if (!(c->duty_factor[i] > 0 && c->duty_factor[i] <= 1) || !(c->stance_duration[i] > 0)) { err = "bad gait timing"; return RG_MPC_ERR_INVALID; }
     if (c->init_state[i] != RG_LEG_SWING && c->init_state[i] != RG_LEG_STANCE) { err = "init_state must be SWING or STANCE"; return RG_MPC_ERR_INVALID; }
   }
-  d->H = c->horizon; d->window = c->window; d->kin_mode = c->kin_mode; d->ik_iters = c->ik_iters; d->admm_iters = c->admm_iters; d->accel_from = c->admm_accel;
+  d->H = c->horizon; d->window = c->window; d->kin_mode = c->kin_mode; d->ik_iters = c->ik_iters; d->admm_iters = c->admm_iters; d->accel_from = c->admm_accel; d->accel_k[0] = 0.9; d->accel_k[1] = 0.98; d->accel_k[2] = 0.5; d->accel_k[3] = 0.999;
   d->dt = c->dt_plan; d->mass = c->mass; d->inv_mass = 1.0 / c->mass; d->body_height = c->body_height; d->alpha = c->alpha;
   d->mu = c->mu[0]; d->g = c->gravity;
   d->fz_min = c->mass * c->gravity * c->fz_min_scale; d->fz_max = c->mass * c->gravity * c->fz_max_scale;

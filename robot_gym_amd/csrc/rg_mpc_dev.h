@@ -58,6 +58,8 @@ struct DevCfg {
   int solver, warm;
   int plan, admm_switch; // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*); admm_switch: first-stage iterations
   double rho2;           // second-stage ADMM rho (0 = single stage)
+  double accel_k[4];     // thresholds of the extrapolation test {0.9, 0.98, 0.5 (spare), 0.999}: read from here (scalar loads) because as
+                         // literals they were materialised in VGPR pairs at kernel entry and spilled to scratch by every workgroup
   double admm_extrap;    // geometric-extrapolation convergence guard, in units of the movement tolerance (+inf = off)
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
