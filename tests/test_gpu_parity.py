@@ -373,7 +373,7 @@ def _sweep_case(seed):
     return cfg, B, over, dict(state=state, cmd=cmd, t_off=t_off, ticks=5, jitter=0.1, gait=gait, sched_fn=sched_fn)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_SWEEP_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_SWEEP_SEEDS", "24"))))
 def test_randomised_configurations(oracle_lib, seed):
     """Seeded sweep over the configuration space (see _sweep_case).  Everything must match the oracle with no failures."""
     cfg, B, over, kw = _sweep_case(seed)
