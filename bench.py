@@ -3,9 +3,10 @@
 horizon=10 (BASELINE.json).  One "step" = one rg_mpc_step over one batch of synthetic robot
 states already resident in HBM.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without RANK in the environment: starts its own ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 2 --dry-launch                 (CPU: the whole multi-rank protocol over gloo with a stub controller)
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, hipEvent-timed over
 the timed region, algorithmic bytes from DESIGN.md section 5) and, at N=1, "cpu_baseline" (the float64
@@ -33,7 +34,7 @@ BATCH_PER_GPU = 4096
 HORIZON = 10
 EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the timed region
 RING = 50          # state slabs in the input ring = ticks of one 0.5 s trot cycle (measured contacts stay gait-consistent)
-PROFILE_TAG = "r2"
+PROFILE_TAG = "r3"
 # algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off)
 ALGO_BYTES_PER_STEP = 1110
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -205,13 +206,79 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
             "sample": f"{Bs} robots x {ticks} ticks of this workload (seed 0, same per-tick input variation), float64 C oracle with exact active-set QP, OpenMP over robots"}
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks ourselves as a FRESH child
+    process tree -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` -- BEFORE this process
+    has made any GPU call (never an exec of a process that touched the GPU), relay rank 0's JSON line and exit with the
+    child's code.  One process per GPU over RCCL (gloo under --dry-launch)."""
+    import socket
+    import subprocess
+    if not args.dry_launch:
+        have = torch.cuda.device_count()   # counts devices without initialising the GPU
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--force-launcher"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in res.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif res.returncode == 0:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        sys.exit(1)
+    sys.exit(res.returncode)
+
+
+class DryController:
+    """--dry-launch stand-in for BatchedMPCController on CPU: same calls, no GPU, no solver.  It exists so that the
+    multi-rank protocol of this file (rendezvous, barriers, MAX-over-ranks timing, the action all-gather, the per-rank
+    gathers, the JSON contract) runs in the CPU test suite over gloo at world size 2."""
+
+    class _Handle:
+        def profile_stride(self, n): pass
+        def profile_begin(self, n): self.n = n
+        def profile_end(self, stream=None): return 1, [0.001, 0.01, 0.001, 0.0, 0.0, 0.012], [0, 0, 1, 0, 0]
+        def profile_window_names(self): return ["rg_front_kernel", "rg_qp_fused_kernel", "rg_qp_fused_retry_kernel", "-", "-", "step_total"]
+
+    def __init__(self, batch):
+        self.batch = batch
+        self.action = torch.zeros(batch, 60, dtype=torch.float32)
+        self._handle = self._Handle()
+
+    def _stream(self): return None
+    def set_gait(self, **kw): pass
+    def reset_at(self, t0): pass
+    def update_controller_params(self, cmd): pass
+    def get_action(self, t, state):
+        self.action.add_(1.0)
+        return self.action
+    def solver_stats(self): return {"iters_sum": 0, "iters_max": 0, "qp_robots": self.batch, "retried_exact": 0, "failures": 0, "iters_mean": 0.0}
+    def audit_stats(self, reset=False): return {"audited": 0, "audit_over_tol": 0, "audit_max_rel": 0.0, "audit_max_rel_elem": 0.0, "audit_exact_failures": 0, "audit_dropped": 0, "audit_skipped_ticks": 0}
+    def close(self): pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="robots per GPU")
-    ap.add_argument("--allgather", action="store_true", help="also all-gather the action slab over RCCL inside the timed step")
+    ap.add_argument("--allgather", action="store_true", help="`value` includes the RCCL all-gather of the action slab inside the timed step (default: a second timed pass reports it as config.with_allgather_steps_per_s)")
+    ap.add_argument("--dry-launch", action="store_true", help="CPU dry run of the multi-rank protocol: gloo, a stub controller, no GPU")
+    ap.add_argument("--force-launcher", action="store_true", help="start the ranks through self_launch even for --gpus 1 (tests the launcher on a 1-GPU box)")
+    ap.add_argument("--kin-mode", type=int, default=0, help="1 = foot positions / Jacobians from joint angles on the device (chain kinematics replacing controllers/mpc/kinematics.py)")
+    ap.add_argument("--robot", default="ghost")
+    ap.add_argument("--audit-k", type=int, default=None, help="audit lane picks per tick (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
     ap.add_argument("--solver", type=int, default=None, help="0 = ADMM, 1 = exact active set")
@@ -239,21 +306,27 @@ def main():
         args.lookahead = True
     ring = 1 if args.static_inputs else max(1, args.ring)
 
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_launcher):
+        self_launch(args, sys.argv[1:])   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dry = args.dry_launch
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     dist = None
     if "RANK" in os.environ and "WORLD_SIZE" in os.environ:   # launched by torch.distributed.run (any N, also N = 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    elif not dry:
         torch.cuda.set_device(0)
-    device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device("cpu") if dry else torch.device("cuda", torch.cuda.current_device())
 
     from robot_gym_amd.core.config import MPCConfig
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
@@ -283,17 +356,22 @@ def main():
         over["admm_switch"] = args.switch
     if args.lookahead:
         over["contact_lookahead"] = 1
-    cfg = MPCConfig.for_robot("ghost", horizon=args.horizon, **over)
+    if args.kin_mode:
+        over["kin_mode"] = args.kin_mode
+    if args.audit_k is not None:
+        over["audit_k"] = args.audit_k
+    cfg = MPCConfig.for_robot(args.robot, horizon=args.horizon, **over)
     B = args.batch
     fixed_cmd = (0.3, 0.0, 0.0) if args.fixed_cmd else None
     # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard
     gait = synthetic.random_gaits(B, cfg, seed=rank) if args.random_schedule else None
     state, cmd, t_off, slabs = make_input_ring(cfg, B, rank, device, ring, args.jitter, fixed_cmd, gait, args.random_schedule)
-    gathered = torch.empty(world * B, 60, dtype=torch.float32, device=device) if (args.allgather and dist is not None) else None
+    gathered = torch.empty(world * B, 60, dtype=torch.float32, device=device) if dist is not None else None
 
-    def run(slab_list, steps, warmup, events, cfg_run=None):
-        """`warmup` untimed then `steps` timed ticks on a fresh controller; returns (seconds, handle-side profile, stats)."""
-        ctl = BatchedMPCController(B, cfg_run or cfg, device=device, extra_outputs=False)
+    def run(slab_list, steps, warmup, events, cfg_run=None, allgather=False):
+        """`warmup` untimed then `steps` timed ticks on a fresh controller; returns (seconds, handle-side profile, stats).
+        allgather: every step also all-gathers the [B, 60] action slab over the process group (RCCL over xGMI)."""
+        ctl = DryController(B) if dry else BatchedMPCController(B, cfg_run or cfg, device=device, extra_outputs=False)
         if gait is not None:
             ctl.set_gait(**gait)
         ctl.reset_at(-t_off)
@@ -302,15 +380,15 @@ def main():
 
         def one_step(k):
             act = ctl.get_action(0.01 * k, slab_list[k % nslab])
-            if gathered is not None:
+            if allgather:
                 dist.all_gather_into_tensor(gathered, act)
 
         for k in range(warmup):
             one_step(k)
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         if events:
             # per-kernel HIP events on every 4th step of the timed region (an event record costs ~4-5 us of stream time)
             ctl._handle.profile_stride(EVENT_STRIDE)
@@ -318,21 +396,41 @@ def main():
         t0 = time.perf_counter()
         for k in range(steps):
             one_step(warmup + k)
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         el = time.perf_counter() - t0
         prof = ctl._handle.profile_end(ctl._stream()) if events else (0, [0.0] * 6, [0] * 5)
         wn = ctl._handle.profile_window_names()
         stats = ctl.solver_stats()
+        stats["audit"] = ctl.audit_stats()
         return el, prof, stats, wn, ctl
 
-    elapsed, (nprof, kms, robots), stats, wn, ctl = run(slabs, args.steps, args.warmup, not args.no_kernel_events)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+
+    use_ag = bool(args.allgather and dist is not None)
+    elapsed, (nprof, kms, robots), stats, wn, ctl = run(slabs, args.steps, args.warmup, not args.no_kernel_events, allgather=use_ag)
+    elapsed = max_over_ranks(elapsed)
+    # SURVEY.md 8e asks for both rates: the other one (with the all-gather when `value` is without it, and vice versa) from a
+    # second timed pass of the same steps -- only when there is a process group to gather over
+    other_elapsed = None
+    if dist is not None:
+        ctl.close()
+        other_elapsed, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, allgather=not use_ag)
+        other_elapsed = max_over_ranks(other_elapsed)
+    # per-rank kernel times (ms): every rank reports its own hipEvent averages
+    per_rank_kms = None
+    if dist is not None:
+        mine = torch.tensor(list(kms[:6]), dtype=torch.float64, device=device)
+        allk = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allk, mine)
+        per_rank_kms = [[round(float(v), 4) for v in t.tolist()] for t in allk]
 
     # Side measurements (reported separately, never `value`), single GPU only:
     #  - the same steps with ONE frozen input slab (round 1's bench; flatters the cost-class launch order, whose
@@ -340,7 +438,7 @@ def main():
     #  - PCIe-inclusive rate: the gym side holds the robot state on the host -- pinned buffers, one upload of all inputs
     #    and one download of the action slab per tick
     pcie_value = static_value = cold_value = None
-    if world == 1 and dist is None and not args.no_extras:
+    if world == 1 and dist is None and not args.no_extras and not dry:
         from robot_gym_amd.controllers.mpc.batched import PackedState
         names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
         ps = PackedState(B, device)     # what MPCVecEnv uses: one pinned slab -> one H2D copy per tick
@@ -394,6 +492,7 @@ def main():
             if B != BATCH_PER_GPU:
                 wkey = f"b{B}" if wkey == "headline" else f"{wkey}_b{B}"
         prof = load_profile(B, wkey)
+        audit = stats.pop("audit", None)
         out = {
             "metric": f"MPC controller steps/sec (whole node), batch={B} quadrupeds, horizon={args.horizon}",
             "value": value, "unit": "controller steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -403,8 +502,13 @@ def main():
                        "input_schedule": ("one frozen state slab (static inputs)" if ring == 1 else
                                           f"ring of {ring} state slabs resident in HBM, one per tick: v_world / rpy_rate scaled by 1 +- {args.jitter}, roll/pitch +- {0.2 * args.jitter:.3g} rad, foot positions +- {20 * args.jitter:.3g} %, measured contacts following the gait"),
                        "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value, "cold_start_steps_per_s": cold_value,
-                       "robot": "ghost", "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""), "admm_iterations": stats,
-                       "warm_start": warm_on, "kin_mode": cfg.kin_mode, "allgather": bool(gathered is not None),
+                       "robot": cfg.robot, "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""), "admm_iterations": stats,
+                       "warm_start": warm_on, "kin_mode": cfg.kin_mode, "allgather": use_ag,
+                       "with_allgather_steps_per_s": (None if other_elapsed is None else (total_units / (elapsed if use_ag else other_elapsed))),
+                       "without_allgather_steps_per_s": (total_units / elapsed if other_elapsed is None else total_units / (other_elapsed if use_ag else elapsed)),
+                       "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
+                       "kernel_ms_per_rank": per_rank_kms, "dry_launch": dry,
+                       "audit": audit,
                        "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective",
                        "kernel_sources": source_hash()},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -418,7 +522,7 @@ def main():
                          "robots_per_stance_count": robots,
                          "note": "path is instruction-issue/latency-bound, not HBM-bound (SURVEY.md 7.3-2): see issue_view and DESIGN.md section 5"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dry:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, B, fixed_cmd=fixed_cmd, gait_seed=(0 if args.random_schedule else None),
                                                    schedule=args.random_schedule, ring=ring, amp=args.jitter)

@@ -15,7 +15,8 @@
  *     data_ptr()); the library owns only per-robot persistent controller state.
  *   - all work is enqueued on the hipStream_t passed in (NULL = default stream); no hidden
  *     synchronisation in rg_mpc_step / rg_mpc_set_command / rg_mpc_hybrid_to_torque.
- *   - one handle per (device, stream); calls on one handle are not thread-safe.
+ *   - one handle per (device, stream); calls on one handle are not thread-safe.  Every call leaves the calling
+ *     thread's current HIP device as it found it (a process driving several GPUs keeps one handle per device).
  *   - inputs are float32 struct-of-arrays, component-major:  x[c*B + b]  (lane = robot loads
  *     coalesce); outputs are row-major per robot:  action[b*60 + k].
  */
@@ -28,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RG_MPC_ABI_VERSION 2
+#define RG_MPC_ABI_VERSION 3
 #define RG_MPC_MAX_HORIZON 20
 #define RG_MPC_NUM_LEGS 4
 #define RG_MPC_NUM_MOTORS 12
@@ -121,6 +122,20 @@ typedef struct {
   double admm_extrap;       /* 5: third convergence condition -- the distance still to go estimated from the shrink rate of
                                the movement per vote window, m r / (1 - r), must be below admm_extrap * admm_tol * m * g
                                (stops crawling robots from passing the "stopped moving" test early); 0 = off */
+  /* thresholds of the dominant-mode extrapolation (tuned constants, like every other one an explicit field):
+   * a vote jumps when consecutive window displacements d1, d0 satisfy cos^2(d1, d0) > accel_cos2 and the shrink
+   * ratio r = <d1,d0>/<d0,d0> lies in (accel_rmin, accel_rmax); the rate that guards the stopping test of a robot
+   * that has jumped is capped at accel_rate_cap */
+  double accel_cos2;        /* 0.9 */
+  double accel_rmax;        /* 0.98 */
+  double accel_rmin;        /* 0.5 */
+  double accel_rate_cap;    /* 0.999 */
+  /* always-on audit lane: every tick about audit_k pseudo-randomly chosen robots whose ADMM solve CONVERGED are re-solved
+   * by the exact active-set bodies (on a library-owned side stream, overlapped with the following ticks; outputs are never
+   * touched) and the joint torques of the two solutions are compared: rg_mpc_audit_stats.  0 = off */
+  int32_t audit_k;          /* 8 */
+  int32_t reserved3;        /* must be 0 */
+  double audit_tol;         /* 1e-4: per-robot torque error max_j |dtau_j| / max(max_j |tau_j|, 1 N m) counted as over tolerance */
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per
@@ -216,6 +231,18 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
  * plus, under RG_SOLVER_ADMM only, robots ADMM left unconverged). */
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);
+
+/* Audit lane statistics, cumulative since create (or since the last call with reset != 0).  Waits for the audit work
+ * in flight (library side stream) and for `stream`.  audited: robots re-solved exactly next to their converged ADMM
+ * solution; over_tol: of those, robots whose torque error exceeded audit_tol; max_rel: largest per-robot error
+ * max_j |dtau_j| / max(max_j |tau_j|, 1 N m); max_rel_elem: largest per-joint error |dtau_j| / max(|tau_j|, 1 N m);
+ * exact_failures: audit re-solves that broke down (their robots are not counted in `audited`); dropped: picks that
+ * found the tick's audit slots full; skipped_ticks: ticks without an audit because the audit of RG_MPC_AUDIT_RING ticks
+ * earlier had not finished.  Any out pointer may be NULL. */
+#define RG_MPC_AUDIT_RING 4
+#define RG_MPC_AUDIT_SLOTS 64
+int rg_mpc_audit_stats(rg_mpc_handle *h, int64_t *audited, int64_t *over_tol, double *max_rel, double *max_rel_elem,
+                       int64_t *exact_failures, int64_t *dropped, int64_t *skipped_ticks, int32_t reset, void *stream);
 
 /* Per-kernel timing with hipEvents recorded on the step's own stream, between the launches of
  * rg_mpc_step.  begin(max_steps) arms it; every following rg_mpc_step records one event after

@@ -191,6 +191,12 @@ class BatchedMPCController:
         core/simulation.py:175-179), q, qd [S,12,B] -> tau [S,B,12] in one launch."""
         if q.shape != qd.shape or q.dtype != torch.float32 or qd.dtype != torch.float32 or not (q.is_contiguous() and qd.is_contiguous()):
             raise ValueError("q and qd must be contiguous float32 tensors of one shape")
+        if q.device != self.device or qd.device != self.device:
+            raise ValueError(f"q and qd must live on {self.device}")
+        # the kernel reads action[b * 60 + 5 j ..] and writes out[(s * B + b) * 12 + j] through raw pointers: a wrong shape,
+        # dtype, stride or device here is an out-of-bounds device access, not an exception -- so check
+        if not torch.is_tensor(action) or action.dtype != torch.float32 or tuple(action.shape) != (self.batch, 60) or not action.is_contiguous() or action.device != self.device:
+            raise ValueError(f"action must be a contiguous float32 [{self.batch},60] tensor on {self.device}")
         if q.dim() == 2 and tuple(q.shape) == (12, self.batch):
             steps, shape = None, (self.batch, 12)
         elif q.dim() == 3 and tuple(q.shape[1:]) == (12, self.batch):
@@ -199,11 +205,17 @@ class BatchedMPCController:
             raise ValueError(f"q must be [12,{self.batch}] or [S,12,{self.batch}]")
         if out is None:
             out = torch.empty(*shape, dtype=torch.float32, device=self.device)
+        elif not torch.is_tensor(out) or out.dtype != torch.float32 or tuple(out.shape) != shape or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"out must be a contiguous float32 {list(shape)} tensor on {self.device}")
         self._handle.hybrid_to_torque(action.data_ptr(), q.data_ptr(), qd.data_ptr(), out.data_ptr(), self._stream(), substeps=steps)
         return out
 
     def solver_stats(self):
         return self._handle.last_solver_stats(self._stream())
+
+    def audit_stats(self, reset=False):
+        """Audit lane counters (core/mpc_abi.MpcHandle.audit_stats)."""
+        return self._handle.audit_stats(reset, self._stream())
 
     def bin_counts(self):
         return self._handle.last_bin_counts(self._stream())

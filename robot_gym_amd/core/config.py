@@ -69,6 +69,15 @@ class MPCConfig:
     admm_switch: int = 150       # iterations are re-factorised with admm_rho2 and continue from their iterate (0 rho2 = off)
     admm_accel: int = 80         # votes from this iteration on may extrapolate (z, y) along the dominant mode (cuts the crawling robots by a third to a half; 0 = off).  80: only robots well past the population's natural tail (p99.9 ~ 90-115) jump -- measured 20..100: 40 costs the headline 1 %, config 2 4 % and config 5 8 % against 80
     admm_extrap: float = 5.0     # convergence also needs the geometric estimate of the remaining distance below admm_extrap * tol (0 = off)
+    # thresholds of the dominant-mode extrapolation: jump when cos^2 of consecutive window displacements
+    # > accel_cos2 and their shrink ratio r is in (accel_rmin, accel_rmax); rate guard of jumped robots capped at accel_rate_cap
+    accel_cos2: float = 0.9
+    accel_rmax: float = 0.98
+    accel_rmin: float = 0.5
+    accel_rate_cap: float = 0.999
+    audit_k: int = 8             # audit lane: ~audit_k converged ADMM solves per tick are re-solved exactly on a side stream and compared (0 = off)
+    reserved3: int = 0           # must be 0
+    audit_tol: float = 1e-4      # per-robot torque error the audit counts as over tolerance
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

@@ -12,7 +12,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
 # RG_MPC_LIB: load another build of the same C-ABI (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("RG_MPC_LIB") or os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 d = C.c_double
 i32 = C.c_int32
 fp = C.c_void_p
@@ -36,6 +36,8 @@ class CConfig(C.Structure):
         ("ik_max_step", d), ("admm_iters", i32), ("reserved0", i32), ("admm_rho", d), ("admm_relax", d),
         ("admm_tol", d), ("admm_check", i32), ("contact_lookahead", i32), ("warm_start", i32), ("reserved2", i32),
         ("admm_rho2", d), ("admm_switch", i32), ("admm_accel", i32), ("admm_extrap", d),
+        ("accel_cos2", d), ("accel_rmax", d), ("accel_rmin", d), ("accel_rate_cap", d),
+        ("audit_k", i32), ("reserved3", i32), ("audit_tol", d),
     ]
 
 
@@ -49,7 +51,7 @@ class COutPtrs(C.Structure):
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_set_gait", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
            "rg_mpc_hybrid_to_torque_substeps",
-           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_audit_stats", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -85,6 +87,9 @@ def load_library(path=None):
     L.rg_mpc_last_bin_counts.restype = i32
     L.rg_mpc_last_solver_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), fp]
     L.rg_mpc_last_solver_stats.restype = i32
+    L.rg_mpc_audit_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(d), C.POINTER(d), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32, fp]
+    L.rg_mpc_audit_stats.restype = i32
     L.rg_mpc_profile_begin.argtypes = [fp, i32]
     L.rg_mpc_profile_begin.restype = i32
     L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
@@ -189,6 +194,15 @@ class MpcHandle:
         self._check(self._lib.rg_mpc_last_solver_stats(self._h, C.byref(s_), C.byref(m_), C.byref(n_), C.byref(r_), C.byref(f_), stream))
         return {"iters_sum": s_.value, "iters_max": m_.value, "qp_robots": n_.value, "retried_exact": r_.value,
                 "failures": f_.value, "iters_mean": (s_.value / n_.value) if n_.value else 0.0}
+
+    def audit_stats(self, reset=False, stream=None):
+        """Audit lane: converged ADMM solves re-solved exactly on the side stream (cumulative; waits for the work in flight)."""
+        a, o, f_, dr, sk = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        mr, me = d(), d()
+        self._check(self._lib.rg_mpc_audit_stats(self._h, C.byref(a), C.byref(o), C.byref(mr), C.byref(me), C.byref(f_), C.byref(dr), C.byref(sk),
+                                                 1 if reset else 0, stream))
+        return {"audited": a.value, "audit_over_tol": o.value, "audit_max_rel": mr.value, "audit_max_rel_elem": me.value,
+                "audit_exact_failures": f_.value, "audit_dropped": dr.value, "audit_skipped_ticks": sk.value}
 
     def profile_begin(self, max_steps):
         self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))

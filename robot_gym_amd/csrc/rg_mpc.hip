@@ -90,6 +90,28 @@ struct rg_mpc_handle {
   int retry_max_nc = 0;             // ... for robots with up to this many stance legs
   double *gait_buf = nullptr;       // [3][4][B] per-robot stance duration / duty factor / initial phase (rg_mpc_set_gait)
   int *gait_init_buf = nullptr;     // [4][B] per-robot initial leg state
+  // audit lane: exact re-solves of ~audit_k converged robots per tick on a side stream (rg_qp_common.inc)
+  bool audit_on = false;
+  hipStream_t audit_stream = nullptr;
+  hipEvent_t audit_fused[RG_AUDIT_RING] = {};   // recorded on the caller's stream after the ADMM launch that filled the ring entry
+  hipEvent_t audit_done[RG_AUDIT_RING] = {};    // recorded on the side stream after the entry's exact re-solves
+  bool audit_inflight[RG_AUDIT_RING] = {};
+  long long steps = 0;              // rg_mpc_step calls (ring entry and hash seed of the audit picks)
+  long long audit_skipped = 0;      // ticks without capture: the entry's previous audit had not finished
+};
+
+// Every entry point runs on the handle's device and leaves the calling thread's current device as it found it: a process that
+// drives several GPUs (one handle + one stream per device) must not have its device switched under it between
+// its own torch / HIP calls.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess && prev >= 0; }
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 
 static thread_local std::string g_create_err;
@@ -120,7 +142,9 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   // the reference cannot set the horizon at all (mpc_controller.py:47-56 passes none: upstream default 10); 10 and 20
   // (BASELINE configs[4]) are the horizons with compiled and GPU-tested solver bodies
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
-  if (c->reserved0 != 0 || c->reserved2 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (!(c->accel_cos2 > 0 && c->accel_cos2 < 1) || !(c->accel_rmin > 0 && c->accel_rmin < c->accel_rmax && c->accel_rmax < 1) || !(c->accel_rate_cap > 0 && c->accel_rate_cap < 1)) { err = "extrapolation thresholds out of range: 0 < accel_cos2 < 1, 0 < accel_rmin < accel_rmax < 1, 0 < accel_rate_cap < 1"; return RG_MPC_ERR_INVALID; }
+  if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / 2 || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 32] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
@@ -134,7 +158,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
     if (!(c->duty_factor[i] > 0 && c->duty_factor[i] <= 1) || !(c->stance_duration[i] > 0)) { err = "bad gait timing"; return RG_MPC_ERR_INVALID; }
     if (c->init_state[i] != RG_LEG_SWING && c->init_state[i] != RG_LEG_STANCE) { err = "init_state must be SWING or STANCE"; return RG_MPC_ERR_INVALID; }
   }
-  d->H = c->horizon; d->window = c->window; d->kin_mode = c->kin_mode; d->ik_iters = c->ik_iters; d->admm_iters = c->admm_iters; d->accel_from = c->admm_accel; d->accel_k[0] = 0.9; d->accel_k[1] = 0.98; d->accel_k[2] = 0.5; d->accel_k[3] = 0.999;
+  d->H = c->horizon; d->window = c->window; d->kin_mode = c->kin_mode; d->ik_iters = c->ik_iters; d->admm_iters = c->admm_iters; d->accel_from = c->admm_accel; d->accel_k[0] = c->accel_cos2; d->accel_k[1] = c->accel_rmax; d->accel_k[2] = c->accel_rmin; d->accel_k[3] = c->accel_rate_cap; d->audit_tol = c->audit_tol;
   d->dt = c->dt_plan; d->mass = c->mass; d->inv_mass = 1.0 / c->mass; d->body_height = c->body_height; d->alpha = c->alpha;
   d->mu = c->mu[0]; d->g = c->gravity;
   d->fz_min = c->mass * c->gravity * c->fz_min_scale; d->fz_max = c->mass * c->gravity * c->fz_max_scale;
@@ -221,7 +245,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; delete h; return RG_MPC_ERR_INVALID; }
 #define CR(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call " failed: ") + hipGetErrorString(e_); rg_mpc_destroy(h); return RG_MPC_ERR_HIP; } } while (0)
 #define AL(p, n) do { int r_ = dev_alloc(h, &(p), (n)); if (r_) { g_create_err = h->err; rg_mpc_destroy(h); return r_; } } while (0)
-  CR(hipSetDevice(device));
+  DeviceScope dev_(device);
+  CR(dev_.err);
   hipDeviceProp_t prop;
   CR(hipGetDeviceProperties(&prop, device));
   h->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -237,6 +262,16 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.warm_key, B); AL(h->st.bins, RG_NLISTS * B); AL(h->counts2, 2 * RG_NCOUNTS); AL(h->st.iters, B); AL(h->st.ncs, B);
   h->st.counts = h->counts2; h->st.counts_next = h->counts2 + RG_NCOUNTS;
   AL(h->idx_dev, B); AL(h->t0_dev, B);
+  h->audit_on = h->fused && cfg->audit_k > 0;
+  if (h->audit_on) {
+    AL(h->st.audit_rec, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * RG_REC_N); AL(h->st.audit_f, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * 12);
+    AL(h->st.audit_idx, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS); AL(h->st.audit_cnt, RG_AUDIT_RING); AL(h->st.audit_stat, 8);
+    CR(hipStreamCreateWithFlags(&h->audit_stream, hipStreamNonBlocking));
+    for (int k = 0; k < RG_AUDIT_RING; k++) {
+      CR(hipEventCreateWithFlags(&h->audit_fused[k], hipEventDisableTiming));
+      CR(hipEventCreateWithFlags(&h->audit_done[k], hipEventDisableTiming));
+    }
+  }
 #undef CR
 #undef AL
   *out = h;
@@ -251,16 +286,24 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
 
 void rg_mpc_destroy(rg_mpc_handle *h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
-  for (void *p : h->allocs) (void)hipFree(p);
-  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  {
+    DeviceScope dev_(h->device);
+    if (h->audit_stream) (void)hipStreamSynchronize(h->audit_stream);
+    for (int k = 0; k < RG_AUDIT_RING; k++) {
+      if (h->audit_fused[k]) (void)hipEventDestroy(h->audit_fused[k]);
+      if (h->audit_done[k]) (void)hipEventDestroy(h->audit_done[k]);
+    }
+    if (h->audit_stream) (void)hipStreamDestroy(h->audit_stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  }
   delete h;
 }
 
 static int reset_impl(rg_mpc_handle *h, const int32_t *idx_host, const double *t0_host, int32_t n, double t0, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   const int *idx = nullptr;
   const double *t0v = nullptr;
   if (t0_host) {
@@ -293,7 +336,7 @@ int rg_mpc_reset_at(rg_mpc_handle *h, const int32_t *idx_host, const double *t0_
 
 int rg_mpc_set_command(rg_mpc_handle *h, const float *cmd, void *stream) {
   if (!h || !cmd) { if (h) h->err = "set_command: null pointer"; return RG_MPC_ERR_INVALID; }
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   HIPCHK(h, hipMemcpyAsync(h->st.cmd, cmd, sizeof(float) * 3 * h->B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return RG_MPC_OK;
 }
@@ -301,7 +344,7 @@ int rg_mpc_set_command(rg_mpc_handle *h, const float *cmd, void *stream) {
 int rg_mpc_set_gait(rg_mpc_handle *h, const double *stance_duration, const double *duty_factor, const double *init_phase,
                     const int32_t *init_state, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   hipStream_t s = (hipStream_t)stream;
   const size_t n4 = (size_t)4 * h->B;
   if (!stance_duration && !duty_factor && !init_phase && !init_state) {   // back to the config-wide gait
@@ -330,11 +373,25 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (!out->action) { h->err = "step: action output required"; return RG_MPC_ERR_INVALID; }
   if (in->contact_sched && !h->cfg.contact_lookahead) { h->err = "step: contact_sched needs contact_lookahead = 1 in the config"; return RG_MPC_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   const int B = h->B, H = h->cfg.horizon;
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact, in->contact_sched, in->t_robot};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
   { int *t_ = h->st.counts; h->st.counts = h->st.counts_next; h->st.counts_next = t_; }   // this tick's counters were zeroed by the previous tick's front kernel
+  // audit lane: this tick captures into ring entry steps % RING -- unless the exact re-solves that still read the entry
+  // (launched RING ticks ago on the side stream) have not finished, which a host-side query finds out without waiting
+  int ring = -1;
+  h->st.audit_k = 0;
+  if (h->audit_on) {
+    const int r = (int)(h->steps % RG_AUDIT_RING);
+    if (h->audit_inflight[r] && hipEventQuery(h->audit_done[r]) == hipSuccess) h->audit_inflight[r] = false;
+    if (!h->audit_inflight[r]) {
+      ring = r;
+      h->st.audit_k = h->cfg.audit_k; h->st.audit_ring = r;
+      h->st.audit_seed = (unsigned)((unsigned long long)h->steps * 0x632BE5ABull + 0x9E3779B9ull);
+    } else h->audit_skipped++;
+  }
+  h->steps++;
   hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);   // one wave per workgroup: 16 k lanes spread over all CUs
@@ -347,9 +404,18 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
     else HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
-    if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s));
-    else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s));
+    if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));
+    if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
+    else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
     if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
+    if (ring >= 0) {
+      // the same exact bodies, in audit mode, over the captured records: side stream, ordered after the ADMM launch only
+      HIPCHK(h, hipStreamWaitEvent(h->audit_stream, h->audit_fused[ring], 0));
+      if (H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
+      else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
+      HIPCHK(h, hipEventRecord(h->audit_done[ring], h->audit_stream));
+      h->audit_inflight[ring] = true;
+    }
     return RG_MPC_OK;
   }
   // RG_SOLVER_ACTIVE_SET: one exact launch per stance-leg count
@@ -367,7 +433,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
 
 int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
   if (!h || max_steps < 1 || max_steps > 100000) { if (h) h->err = "profile_begin: bad max_steps"; return RG_MPC_ERR_INVALID; }
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   while ((int)h->ev.size() < max_steps * RG_PROF_EV) {
     hipEvent_t e;
     // timing-only events: no system-scope fence when they are recorded (a default event costs ~1.3 us more of stream time per record)
@@ -401,7 +467,7 @@ int rg_mpc_profile_stride(rg_mpc_handle *h, int32_t stride) {
 
 int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void *stream) {
   if (!h || !avg_ms6) { if (h) h->err = "profile_end: null output"; return RG_MPC_ERR_INVALID; }
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
   int n = h->prof_n;
   h->prof_max = 0;
@@ -434,7 +500,7 @@ __global__ void rg_debug_poison_lds_kernel(int ndoubles) {
 
 int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   const int bytes = 160 * 1024;
   static bool attr_done[64] = {};
   if (lds_attr_needed(attr_done)) HIPCHK(h, hipFuncSetAttribute((const void *)rg_debug_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -446,7 +512,7 @@ int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream) {
 int rg_mpc_hybrid_to_torque_substeps(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, int32_t substeps, void *stream) {
   if (!h || !action || !q || !qd || !tau) { if (h) h->err = "hybrid_to_torque: null pointer"; return RG_MPC_ERR_INVALID; }
   if (substeps < 1 || substeps > 1024) { h->err = "hybrid_to_torque: substeps out of range [1,1024]"; return RG_MPC_ERR_INVALID; }
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   const int total = h->B * 12;
   hipLaunchKernelGGL(rg_hybrid_to_torque_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, action, q, qd, tau, h->B, substeps);
   HIPCHK(h, hipGetLastError());
@@ -460,7 +526,7 @@ int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
   int cnt[RG_NCOUNTS], per_nc[5];
   HIPCHK(h, hipMemcpy(cnt, h->st.counts, sizeof(cnt), hipMemcpyDeviceToHost));
@@ -482,9 +548,34 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
   return RG_MPC_OK;
 }
 
+int rg_mpc_audit_stats(rg_mpc_handle *h, int64_t *audited, int64_t *over_tol, double *max_rel, double *max_rel_elem,
+                       int64_t *exact_failures, int64_t *dropped, int64_t *skipped_ticks, int32_t reset, void *stream) {
+  if (!h) return RG_MPC_ERR_INVALID;
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long st8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (h->audit_on) {
+    HIPCHK(h, hipStreamSynchronize(h->audit_stream));
+    for (int k = 0; k < RG_AUDIT_RING; k++) h->audit_inflight[k] = false;
+    HIPCHK(h, hipMemcpy(st8, h->st.audit_stat, sizeof(st8), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->st.audit_stat, 0, sizeof(st8)));
+  }
+  double mr, me;
+  memcpy(&mr, &st8[2], sizeof(double)); memcpy(&me, &st8[3], sizeof(double));
+  if (audited) *audited = (int64_t)st8[0];
+  if (over_tol) *over_tol = (int64_t)st8[1];
+  if (max_rel) *max_rel = mr;
+  if (max_rel_elem) *max_rel_elem = me;
+  if (exact_failures) *exact_failures = (int64_t)st8[4];
+  if (dropped) *dropped = (int64_t)st8[5];
+  if (skipped_ticks) *skipped_ticks = h->audit_skipped;
+  if (reset) h->audit_skipped = 0;
+  return RG_MPC_OK;
+}
+
 int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_legs_B, void *stream) {
   if (!h || (!iters_B && !stance_legs_B)) return RG_MPC_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
   if (iters_B) HIPCHK(h, hipMemcpy(iters_B, h->st.iters, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
   if (stance_legs_B) HIPCHK(h, hipMemcpy(stance_legs_B, h->st.ncs, sizeof(int) * (size_t)h->B, hipMemcpyDeviceToHost));
@@ -493,7 +584,7 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
 
 int rg_mpc_last_bin_counts(rg_mpc_handle *h, int32_t *out5, void *stream) {
   if (!h || !out5) return RG_MPC_ERR_INVALID;
-  HIPCHK(h, hipSetDevice(h->device));
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
   int tmp[5];
   { int r_ = host_bin_counts(h, tmp); if (r_) return r_; }

@@ -58,8 +58,10 @@ struct DevCfg {
   int solver, warm;
   int plan, admm_switch; // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*); admm_switch: first-stage iterations
   double rho2;           // second-stage ADMM rho (0 = single stage)
-  double accel_k[4];     // thresholds of the extrapolation test {0.9, 0.98, 0.5 (spare), 0.999}: read from here (scalar loads) because as
-                         // literals they were materialised in VGPR pairs at kernel entry and spilled to scratch by every workgroup
+  double accel_k[4];     // thresholds of the extrapolation test {accel_cos2 0.9, accel_rmax 0.98, accel_rmin 0.5, accel_rate_cap 0.999}
+                         // (rg_mpc_config): read from here (scalar loads) because as literals they were materialised in VGPR pairs at
+                         // kernel entry and spilled to scratch by every workgroup
+  double audit_tol;      // audit lane: per-robot torque error counted as over tolerance
   double admm_extrap;    // geometric-extrapolation convergence guard, in units of the movement tolerance (+inf = off)
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
@@ -87,7 +89,19 @@ struct DevState {
   // optional per-robot gait timing (rg_mpc_set_gait), [4][B] each; null = the config-wide gait of DevCfg
   const double *g_stance, *g_duty, *g_phase;
   const int *g_init;
+  // audit lane (rg_qp_common.inc: audit_capture / audit_compare).  The ADMM bodies copy the record and the first-step forces
+  // of ~audit_k converged robots per tick into slot ring `audit_ring`; the exact bodies re-solve them on a side stream.
+  double *audit_rec;    // [RG_AUDIT_RING][RG_AUDIT_SLOTS][RG_REC_N]
+  double *audit_f;      // [RG_AUDIT_RING][RG_AUDIT_SLOTS][12] ADMM first-step forces (as in the grf output)
+  int *audit_idx;       // [RG_AUDIT_RING][RG_AUDIT_SLOTS] robot | re-solve list (stance legs) << 24
+  int *audit_cnt;       // [RG_AUDIT_RING] picks of the tick that owns the ring entry (may exceed RG_AUDIT_SLOTS: the rest is dropped)
+  unsigned long long *audit_stat;   // [8] audited, over_tol, max_rel bits, max_rel_elem bits, exact failures, dropped
+  int audit_k;          // expected picks per tick for THIS launch (0: no capture)
+  int audit_ring;       // ring entry of this tick
+  unsigned audit_seed;  // per-tick hash seed
 };
+#define RG_AUDIT_RING 4
+#define RG_AUDIT_SLOTS 64
 
 struct DevIn {
   const float *rpy, *rpy_rate, *v_world, *quat, *q, *foot_pos, *jac, *cmd;

@@ -119,8 +119,17 @@ def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0"
         o["bins"] = ctl.bin_counts()
         o["solver_stats"] = ctl.solver_stats()
         outs.append(o)
+    if outs:
+        outs[-1]["audit"] = ctl.audit_stats()   # audit lane, cumulative over the run (waits for the side stream)
     ctl.close()
     return outs
+
+
+def assert_audit_clean(audit, min_audited=0):
+    """The audit lane (exact re-solves of converged ADMM robots on the side stream) found nothing over tolerance."""
+    assert audit["audit_over_tol"] == 0 and audit["audit_exact_failures"] == 0, audit
+    assert audit["audited"] >= min_audited, audit
+    assert audit["audit_max_rel"] <= 1e-4, audit
 
 
 def compare_tick(og, oo, tol=1e-4):

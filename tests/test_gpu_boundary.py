@@ -47,6 +47,18 @@ def test_motor_model_over_action_repeat_matches_reference_goldens():
     np.testing.assert_array_equal(one.cpu().numpy(), tau[3].cpu().numpy())
     with pytest.raises(ValueError):
         ctl.hybrid_to_torque(act, q[:, :11].contiguous(), qd[:, :11].contiguous())
+    # the raw pointers behind `action` and `out` are checked too (wrong shape / dtype / stride / device would be an
+    # out-of-bounds device access, not an exception)
+    for bad_act in (act[:, :59].contiguous(), act.double(), act.t().contiguous().t(), act.cpu(), act[: n - 1].contiguous()):
+        with pytest.raises(ValueError):
+            ctl.hybrid_to_torque(bad_act, q, qd)
+    for bad_out in (torch.empty(n, 12, device="cuda"), torch.empty(S, n, 12, dtype=torch.float64, device="cuda"), torch.empty(S, n, 12)):
+        with pytest.raises(ValueError):
+            ctl.hybrid_to_torque(act, q, qd, out=bad_out)
+    with pytest.raises(ValueError):
+        ctl.hybrid_to_torque(act, q.cpu(), qd.cpu())
+    good = torch.empty(S, n, 12, device="cuda")
+    assert ctl.hybrid_to_torque(act, q, qd, out=good) is good and torch.equal(good, tau)
     ctl.close()
 
 
@@ -240,7 +252,8 @@ def test_parity_at_baseline_batch_4096(oracle_lib):
         assert m["leg_state_mismatch"] == 0 and m["desired_mismatch"] == 0 and m["phase_bits"] == 0, m
         assert m["tau_rel_max"] <= 1e-4 and m["grf_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, m
         worst = max(worst, m["tau_rel_max"])
-    print("worst relative torque error over 8192 robot-ticks:", worst)
+    helpers.assert_audit_clean(gpu[-1]["audit"], min_audited=4)
+    print("worst relative torque error over 8192 robot-ticks:", worst, gpu[-1]["audit"])
 
 
 def test_step_argument_validation_reports_errors():
@@ -335,7 +348,8 @@ def test_parity_config5_batch_4096_horizon_20(oracle_lib):
         assert m["leg_state_mismatch"] == 0 and m["desired_mismatch"] == 0 and m["phase_bits"] == 0, m
         assert m["tau_rel_max"] <= 1e-4 and m["grf_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, m
         worst = max(worst, m["tau_rel_max"])
-    print("config 5, worst relative torque error over 8192 robot-ticks:", worst, gpu[-1]["solver_stats"])
+    helpers.assert_audit_clean(gpu[-1]["audit"], min_audited=4)
+    print("config 5, worst relative torque error over 8192 robot-ticks:", worst, gpu[-1]["solver_stats"], gpu[-1]["audit"])
 
 
 def test_batch_32768_properties_and_sampled_parity(oracle_lib):
@@ -366,6 +380,7 @@ def test_batch_32768_properties_and_sampled_parity(oracle_lib):
         assert m["tau_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5 and m["gains"] == 0.0, (k, m)
     stats, bins = ctl.solver_stats(), ctl.bin_counts()
     assert stats["failures"] == 0 and sum(bins) == B and np.isfinite(act).all()
+    helpers.assert_audit_clean(ctl.audit_stats(), min_audited=6)
     f = -ctl.extra["grf"].cpu().numpy().astype(np.float64).reshape(B, 4, 3)
     stance = ctl.extra["desired_state"].cpu().numpy() == 1
     mg = cfg.mass * cfg.gravity
@@ -395,6 +410,27 @@ def test_bench_under_torchrun_world_size_1(tmp_path):
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["allgather"] is True and out["config"]["admm_iterations"]["failures"] == 0
     assert out["roofline"]["kernel"] == "rg_qp_fused_kernel" and out["roofline"]["avg_launch_ms"] > 0
+
+
+def test_bench_self_launch_one_rank(tmp_path):
+    """`python bench.py --gpus N` starts its own ranks when RANK is not set (the driver's form for the scaling runs).  On the
+    one GPU of a test box: --force-launcher makes --gpus 1 go through the same launcher -- a fresh torch.distributed.run child,
+    started before the parent has touched the GPU -- and the line reports the RCCL world, per-rank kernel times and both the
+    with- and without-all-gather rates."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-launcher", "--steps", "3", "--warmup", "1",
+                          "--batch", "512", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    c = out["config"]
+    assert out["n_gpus"] == 1 and c["rccl_ranks"] == 1 and c["backend"] == "nccl" and c["dry_launch"] is False
+    assert c["with_allgather_steps_per_s"] > 0 and c["without_allgather_steps_per_s"] == out["value"]
+    assert len(c["kernel_ms_per_rank"]) == 1 and c["kernel_ms_per_rank"][0][1] > 0
+    assert c["admm_iterations"]["failures"] == 0 and c["audit"]["audit_over_tol"] == 0
 
 
 def test_set_gait_validation_and_return_to_config_gait(oracle_lib):

@@ -480,3 +480,56 @@ def test_horizon_20_bench_inputs_need_no_exact_pass(accel):
     for act, it, nc, stats in _bench_like_run(MPCConfig.for_robot("ghost", horizon=20, admm_accel=accel), B, 6):
         assert stats["failures"] == 0 and stats["retried_exact"] == 0, stats
         assert it[nc >= 3].mean() < 90 and it[nc == 2].mean() < 80, (it[nc >= 3].mean(), it[nc == 2].mean())
+
+
+def _bench_like_run(cfg, B, ticks, seed=0, jitter=0.1, horizon_sched=False):
+    """`ticks` ticks of the bench's input schedule on a fresh controller; returns (actions of the last tick, controller)."""
+    import torch
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed)
+    ctl = BatchedMPCController(B, cfg, extra_outputs=False)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    acts = []
+    for k in range(ticks):
+        st = helpers.perturb(state, k, jitter)
+        dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+        dev["contact"] = torch.from_numpy(synthetic.gait_consistent_contacts(cfg, 0.01 * k + t_off, state["_flip"])).cuda()
+        acts.append(ctl.get_action(0.01 * k, dev).cpu().numpy().copy())
+    return acts, ctl
+
+
+@pytest.mark.parametrize("horizon,B,ticks", [(10, 4096, 30), (20, 1024, 10)])
+def test_audit_lane_re_solves_converged_robots_and_finds_nothing(horizon, B, ticks):
+    """Always-on audit: ~audit_k converged ADMM solves per tick go through the exact active-set bodies on the side stream;
+    with the library defaults nothing may come back over 1e-4, no exact solve may fail, and the count must be about
+    audit_k x ticks (Poisson picks; ticks whose ring entry is still busy are skipped and counted)."""
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon)
+    acts, ctl = _bench_like_run(cfg, B, ticks)
+    a = ctl.audit_stats()
+    ctl.close()
+    helpers.assert_audit_clean(a)
+    expect = cfg.audit_k * (ticks - a["audit_skipped_ticks"])
+    assert 0.5 * expect <= a["audited"] + a["audit_dropped"] <= 1.6 * expect, (a, expect)
+    assert 0.0 < a["audit_max_rel"] <= 1e-4 and a["audit_max_rel_elem"] <= 1e-3, a
+    print("audit", horizon, a)
+
+
+def test_audit_lane_notices_a_sloppy_exit_and_never_touches_outputs():
+    """The audit must be able to fail: with the stopping rules loosened 1000x (and the guards off) converged robots are far
+    from the optimum and the audit says so.  And it only observes: actions with and without the audit lane are bit-identical."""
+    cfg = MPCConfig.for_robot("ghost")
+    acts_on, ctl = _bench_like_run(cfg, 2048, 6)
+    ctl.close()
+    acts_off, ctl = _bench_like_run(MPCConfig.for_robot("ghost", audit_k=0), 2048, 6)
+    a0 = ctl.audit_stats()
+    ctl.close()
+    assert a0["audited"] == 0
+    for x, y in zip(acts_on, acts_off):
+        assert np.array_equal(x, y)
+    sloppy = MPCConfig.for_robot("ghost", admm_tol=1e-3, admm_extrap=0.0, admm_accel=0, audit_k=32)
+    _, ctl = _bench_like_run(sloppy, 2048, 6)
+    a = ctl.audit_stats()
+    ctl.close()
+    assert a["audited"] >= 50 and a["audit_over_tol"] > 0 and a["audit_max_rel"] > 1e-4, a
+    print("sloppy exit seen by the audit:", a)

@@ -46,6 +46,32 @@ def test_all_gather_actions_world_size_2_gloo(tmp_path):
     assert [open(tmp_path / f"r{r}").read() for r in range(2)] == ["ok", "ok"]
 
 
+def test_bench_launches_its_own_ranks_dry_run_world_size_2():
+    """`python bench.py --gpus 2` without RANK in the environment must start its own ranks (the driver's form for the
+    scaling runs): a fresh torch.distributed.run child with two processes.  --dry-launch runs the whole protocol on CPU over
+    gloo with a stub controller: rendezvous on 127.0.0.1, barriers, MAX-over-ranks timing, both all-gather variants, the
+    per-rank kernel-time gather and the JSON contract."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch", "--batch", "64", "--steps", "3",
+                          "--warmup", "1", "--ring", "4"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # rank 0's JSON line and nothing else on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["value"] > 0
+    c = out["config"]
+    assert c["dry_launch"] is True and c["rccl_ranks"] == 2 and c["backend"] == "gloo" and len(c["kernel_ms_per_rank"]) == 2
+    assert c["with_allgather_steps_per_s"] > 0 and c["without_allgather_steps_per_s"] == out["value"]
+    assert c["sharding"].startswith("2 x 64 robots")
+    # a rank count the node cannot serve is refused before anything is launched
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "GPU(s)" in res.stderr
+
+
 def test_synthetic_states_are_deterministic_and_shaped():
     cfg = MPCConfig.for_robot("ghost")
     a, ca, ta = synthetic.make_states(128, cfg, seed=3)
