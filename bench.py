@@ -263,7 +263,7 @@ class DryController:
         self.action.add_(1.0)
         return self.action
     def solver_stats(self): return {"iters_sum": 0, "iters_max": 0, "qp_robots": self.batch, "retried_exact": 0, "failures": 0, "iters_mean": 0.0}
-    def audit_stats(self, reset=False): return {"audited": 0, "audit_over_tol": 0, "audit_max_rel": 0.0, "audit_max_rel_elem": 0.0, "audit_exact_failures": 0, "audit_dropped": 0, "audit_skipped_ticks": 0}
+    def audit_stats(self, reset=False): return {"audited": 0, "audit_over_tol": 0, "audit_max_rel": 0.0, "audit_max_rel_elem": 0.0, "audit_exact_failures": 0, "audit_dropped": 0}
     def close(self): pass
 
 

@@ -88,7 +88,7 @@ def load_library(path=None):
     L.rg_mpc_last_solver_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), fp]
     L.rg_mpc_last_solver_stats.restype = i32
     L.rg_mpc_audit_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(d), C.POINTER(d), C.POINTER(C.c_int64),
-                                     C.POINTER(C.c_int64), C.POINTER(C.c_int64), i32, fp]
+                                     C.POINTER(C.c_int64), i32, fp]
     L.rg_mpc_audit_stats.restype = i32
     L.rg_mpc_profile_begin.argtypes = [fp, i32]
     L.rg_mpc_profile_begin.restype = i32
@@ -197,12 +197,12 @@ class MpcHandle:
 
     def audit_stats(self, reset=False, stream=None):
         """Audit lane: converged ADMM solves re-solved exactly on the side stream (cumulative; waits for the work in flight)."""
-        a, o, f_, dr, sk = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        a, o, f_, dr = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         mr, me = d(), d()
-        self._check(self._lib.rg_mpc_audit_stats(self._h, C.byref(a), C.byref(o), C.byref(mr), C.byref(me), C.byref(f_), C.byref(dr), C.byref(sk),
+        self._check(self._lib.rg_mpc_audit_stats(self._h, C.byref(a), C.byref(o), C.byref(mr), C.byref(me), C.byref(f_), C.byref(dr),
                                                  1 if reset else 0, stream))
         return {"audited": a.value, "audit_over_tol": o.value, "audit_max_rel": mr.value, "audit_max_rel_elem": me.value,
-                "audit_exact_failures": f_.value, "audit_dropped": dr.value, "audit_skipped_ticks": sk.value}
+                "audit_exact_failures": f_.value, "audit_dropped": dr.value}
 
     def profile_begin(self, max_steps):
         self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))

@@ -97,7 +97,6 @@ struct rg_mpc_handle {
   hipEvent_t audit_done[RG_AUDIT_RING] = {};    // recorded on the side stream after the entry's exact re-solves
   bool audit_inflight[RG_AUDIT_RING] = {};
   long long steps = 0;              // rg_mpc_step calls (ring entry and hash seed of the audit picks)
-  long long audit_skipped = 0;      // ticks without capture: the entry's previous audit had not finished
 };
 
 // Every entry point runs on the handle's device and leaves the calling thread's current device as it found it: a process that
@@ -144,7 +143,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
   if (!(c->accel_cos2 > 0 && c->accel_cos2 < 1) || !(c->accel_rmin > 0 && c->accel_rmin < c->accel_rmax && c->accel_rmax < 1) || !(c->accel_rate_cap > 0 && c->accel_rate_cap < 1)) { err = "extrapolation thresholds out of range: 0 < accel_cos2 < 1, 0 < accel_rmin < accel_rmax < 1, 0 < accel_rate_cap < 1"; return RG_MPC_ERR_INVALID; }
-  if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / 2 || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 32] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
+  if (c->audit_k < 0 || c->audit_k * RG_AUDIT_PERIOD * 2 > RG_AUDIT_SLOTS || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
@@ -266,7 +265,13 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   if (h->audit_on) {
     AL(h->st.audit_rec, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * RG_REC_N); AL(h->st.audit_f, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * 12);
     AL(h->st.audit_idx, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS); AL(h->st.audit_cnt, RG_AUDIT_RING); AL(h->st.audit_stat, 8);
-    CR(hipStreamCreateWithFlags(&h->audit_stream, hipStreamNonBlocking));
+    {
+      // lowest priority: the exact re-solves fill the gaps the tick's own launches leave (the tail of the ADMM launch), they
+      // must not compete with them for CUs
+      int prio_low = 0, prio_high = 0;
+      CR(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+      CR(hipStreamCreateWithPriority(&h->audit_stream, hipStreamNonBlocking, prio_low));
+    }
     for (int k = 0; k < RG_AUDIT_RING; k++) {
       CR(hipEventCreateWithFlags(&h->audit_fused[k], hipEventDisableTiming));
       CR(hipEventCreateWithFlags(&h->audit_done[k], hipEventDisableTiming));
@@ -378,18 +383,16 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   DevIn di{in->rpy, in->rpy_rate, in->v_world, in->quat, in->q, in->foot_pos, in->jac, in->cmd, in->contact, in->contact_sched, in->t_robot};
   DevOut dout{out->action, out->grf, out->tau_stance, out->phase, out->foot_target, out->v_body, out->leg_state, out->desired_state};
   { int *t_ = h->st.counts; h->st.counts = h->st.counts_next; h->st.counts_next = t_; }   // this tick's counters were zeroed by the previous tick's front kernel
-  // audit lane: this tick captures into ring entry steps % RING -- unless the exact re-solves that still read the entry
-  // (launched RING ticks ago on the side stream) have not finished, which a host-side query finds out without waiting
+  // audit lane: this tick captures into ring entry steps % RING.  The exact re-solves that read the entry's previous
+  // contents were launched RING ticks ago on the side stream; this stream waits for them before the entry is rewritten (an
+  // already-signalled event in the steady state: the host runs many ticks ahead of the GPU, so it cannot tell by a query)
   int ring = -1;
   h->st.audit_k = 0;
-  if (h->audit_on) {
-    const int r = (int)(h->steps % RG_AUDIT_RING);
-    if (h->audit_inflight[r] && hipEventQuery(h->audit_done[r]) == hipSuccess) h->audit_inflight[r] = false;
-    if (!h->audit_inflight[r]) {
-      ring = r;
-      h->st.audit_k = h->cfg.audit_k; h->st.audit_ring = r;
-      h->st.audit_seed = (unsigned)((unsigned long long)h->steps * 0x632BE5ABull + 0x9E3779B9ull);
-    } else h->audit_skipped++;
+  if (h->audit_on && h->steps % RG_AUDIT_PERIOD == 0) {
+    ring = (int)((h->steps / RG_AUDIT_PERIOD) % RG_AUDIT_RING);
+    if (h->audit_inflight[ring]) HIPCHK(h, hipStreamWaitEvent(s, h->audit_done[ring], 0));
+    h->st.audit_k = h->cfg.audit_k * RG_AUDIT_PERIOD; h->st.audit_ring = ring;
+    h->st.audit_seed = (unsigned)((unsigned long long)h->steps * 0x632BE5ABull + 0x9E3779B9ull);
   }
   h->steps++;
   hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
@@ -411,8 +414,13 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     if (ring >= 0) {
       // the same exact bodies, in audit mode, over the captured records: side stream, ordered after the ADMM launch only
       HIPCHK(h, hipStreamWaitEvent(h->audit_stream, h->audit_fused[ring], 0));
-      if (H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
-      else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
+      if (H == 10) {
+        // three / four legs (and every robot of a contact schedule, entries of "four legs") on the 256-lane bodies, one / two
+        // legs on the one-wave exact bodies: an exact solve then keeps one SIMD busy, not a whole CU
+        HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 2));
+        HIPCHK(h, (launch_qp_tile_exact<2, 10, 8, 3>(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, false, h->st.audit_k + h->st.audit_k / 4)));
+        HIPCHK(h, (launch_qp_tile_exact<1, 10, 4, 3>(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, false, 4)));
+      } else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
       HIPCHK(h, hipEventRecord(h->audit_done[ring], h->audit_stream));
       h->audit_inflight[ring] = true;
     }
@@ -549,7 +557,7 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
 }
 
 int rg_mpc_audit_stats(rg_mpc_handle *h, int64_t *audited, int64_t *over_tol, double *max_rel, double *max_rel_elem,
-                       int64_t *exact_failures, int64_t *dropped, int64_t *skipped_ticks, int32_t reset, void *stream) {
+                       int64_t *exact_failures, int64_t *dropped, int32_t reset, void *stream) {
   if (!h) return RG_MPC_ERR_INVALID;
   DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
   HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
@@ -568,8 +576,6 @@ int rg_mpc_audit_stats(rg_mpc_handle *h, int64_t *audited, int64_t *over_tol, do
   if (max_rel_elem) *max_rel_elem = me;
   if (exact_failures) *exact_failures = (int64_t)st8[4];
   if (dropped) *dropped = (int64_t)st8[5];
-  if (skipped_ticks) *skipped_ticks = h->audit_skipped;
-  if (reset) h->audit_skipped = 0;
   return RG_MPC_OK;
 }
 

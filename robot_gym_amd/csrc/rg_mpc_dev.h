@@ -101,7 +101,12 @@ struct DevState {
   unsigned audit_seed;  // per-tick hash seed
 };
 #define RG_AUDIT_RING 4
-#define RG_AUDIT_SLOTS 64
+#define RG_AUDIT_SLOTS 128
+// The audit runs on every RG_AUDIT_PERIOD-th tick with RG_AUDIT_PERIOD x audit_k expected picks: one exact solve keeps a whole
+// CU for 100-250 us, and one side-stream launch per tick (its solves in parallel, but launches of one stream in series) took
+// longer than the tick itself -- the caller's stream then stalled on ring reuse (measured: -20 %).  Same audited robots per
+// second, a quarter of the launches.
+#define RG_AUDIT_PERIOD 4
 
 struct DevIn {
   const float *rpy, *rpy_rate, *v_world, *quat, *q, *foot_pos, *jac, *cmd;
