@@ -37,4 +37,5 @@ for name, robot, kw, B, ticks, seed, sched in cases:
                              / np.maximum(np.abs(o["action"].reshape(B, 12, 5)[:, :, 4]).max(1), 1.0) for g, o in zip(gpu, orc)])
     print(f"{name:16s} robot-ticks {allerr.size:7d}  p50 %.1e p99 %.1e p99.9 %.1e max %.1e" % tuple(np.percentile(allerr, [50, 99, 99.9, 100])),
           " per-joint max %.1e  grf %.1e  mean iterations %.1f  exact re-solves %d  failures %d" % (max(m["tau_rel_elem_max"] for m in w), max(m["grf_rel_max"] for m in w),
-          gpu[-1]["solver_stats"]["iters_mean"], sum(g["solver_stats"]["retried_exact"] for g in gpu), sum(g["solver_stats"]["failures"] for g in gpu)), over)
+          gpu[-1]["solver_stats"]["iters_mean"], sum(g["solver_stats"]["retried_exact"] for g in gpu), sum(g["solver_stats"]["failures"] for g in gpu)), over,
+          "audit", {k: (v if isinstance(v, int) else float("%.2e" % v)) for k, v in gpu[-1]["audit"].items()})
