@@ -133,7 +133,7 @@ typedef struct {
   /* always-on audit lane: on average audit_k pseudo-randomly chosen robots per tick whose ADMM solve CONVERGED are re-solved
    * by the exact active-set bodies (on a library-owned low-priority side stream, overlapped with the following ticks; outputs
    * are never touched) and the joint torques of the two solutions are compared: rg_mpc_audit_stats.  The picks are made on
-   * every RG_MPC_AUDIT_PERIOD-th tick, RG_MPC_AUDIT_PERIOD x audit_k of them.  0 = off, at most 16 */
+   * the first tick and then on every RG_MPC_AUDIT_PERIOD-th one, RG_MPC_AUDIT_PERIOD x audit_k of them.  0 = off, at most 16 */
   int32_t audit_k;          /* 8 */
   int32_t reserved3;        /* must be 0 */
   double audit_tol;         /* 1e-4: per-robot torque error max_j |dtau_j| / max(max_j |tau_j|, 1 N m) counted as over tolerance */
@@ -241,8 +241,8 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
  * found the tick's RG_MPC_AUDIT_SLOTS slots full.  Any out pointer may be NULL.  The tick that reuses a slot ring entry
  * (RG_MPC_AUDIT_RING x RG_MPC_AUDIT_PERIOD ticks later) waits on its stream for the entry's re-solves. */
 #define RG_MPC_AUDIT_RING 4
-#define RG_MPC_AUDIT_SLOTS 128
-#define RG_MPC_AUDIT_PERIOD 4
+#define RG_MPC_AUDIT_SLOTS 256
+#define RG_MPC_AUDIT_PERIOD 8
 int rg_mpc_audit_stats(rg_mpc_handle *h, int64_t *audited, int64_t *over_tol, double *max_rel, double *max_rel_elem,
                        int64_t *exact_failures, int64_t *dropped, int32_t reset, void *stream);
 

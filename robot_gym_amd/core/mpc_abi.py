@@ -13,6 +13,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
 LIB_PATH = os.environ.get("RG_MPC_LIB") or os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
 
 ABI_VERSION = 3
+AUDIT_PERIOD = 8   # RG_MPC_AUDIT_PERIOD: the audit lane picks on the first tick and then on every 8th one (ticks 4, 12, 20 ...)
 d = C.c_double
 i32 = C.c_int32
 fp = C.c_void_p

@@ -388,8 +388,8 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // already-signalled event in the steady state: the host runs many ticks ahead of the GPU, so it cannot tell by a query)
   int ring = -1;
   h->st.audit_k = 0;
-  if (h->audit_on && h->steps % RG_AUDIT_PERIOD == 0) {
-    ring = (int)((h->steps / RG_AUDIT_PERIOD) % RG_AUDIT_RING);
+  if (h->audit_on && (h->steps == 0 || h->steps % RG_AUDIT_PERIOD == RG_AUDIT_PERIOD / 2)) {
+    ring = (int)(((h->steps + RG_AUDIT_PERIOD / 2) / RG_AUDIT_PERIOD) % RG_AUDIT_RING);
     if (h->audit_inflight[ring]) HIPCHK(h, hipStreamWaitEvent(s, h->audit_done[ring], 0));
     h->st.audit_k = h->cfg.audit_k * RG_AUDIT_PERIOD; h->st.audit_ring = ring;
     h->st.audit_seed = (unsigned)((unsigned long long)h->steps * 0x632BE5ABull + 0x9E3779B9ull);

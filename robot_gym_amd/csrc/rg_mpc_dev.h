@@ -101,12 +101,14 @@ struct DevState {
   unsigned audit_seed;  // per-tick hash seed
 };
 #define RG_AUDIT_RING 4
-#define RG_AUDIT_SLOTS 128
-// The audit runs on every RG_AUDIT_PERIOD-th tick with RG_AUDIT_PERIOD x audit_k expected picks: one exact solve keeps a whole
-// CU for 100-250 us, and one side-stream launch per tick (its solves in parallel, but launches of one stream in series) took
-// longer than the tick itself -- the caller's stream then stalled on ring reuse (measured: -20 %).  Same audited robots per
-// second, a quarter of the launches.
-#define RG_AUDIT_PERIOD 4
+#define RG_AUDIT_SLOTS 256
+// The audit runs on the first tick and then on every RG_AUDIT_PERIOD-th one, with RG_AUDIT_PERIOD x audit_k expected picks: an
+// exact solve takes 100-350 us, and one side-stream launch per tick (its solves in parallel, but launches of one stream in
+// series) took longer than the tick itself -- the caller's stream then stalled on ring reuse (measured: -20 %).  Same
+// audited robots per second, an eighth of the launches.  Measured and not kept: every exact solve on a one-wave body (the
+// wrench-space one for three and four legs takes 425 us against 300 us on 256 lanes) with the three stance-leg classes on
+// three side streams (each cross-stream event costs the caller's stream ~8 us: -7 % instead of -5 %).
+#define RG_AUDIT_PERIOD 8
 
 struct DevIn {
   const float *rpy, *rpy_rate, *v_world, *quat, *q, *foot_pos, *jac, *cmd;
