@@ -33,6 +33,7 @@ class BatchSlotController(Controller):
         self.reset_clock = None             # clock value of a reset the batch has not applied yet
         self.phase = "idle"                 # "capture": get_action suspends the env's step; "replay": returns `action`
         self.action = None
+        self._captured = None
         self.reset()
 
     @property
@@ -61,10 +62,21 @@ class BatchSlotController(Controller):
         else:
             raise ValueError("params must be (vx, wz) or (vx, vy, wz)")
 
+    def begin_replay(self, action_row):
+        """Second pass of a two-pass tick (envs without pre_step / post_step): get_action() will hand out `action_row`,
+        after checking that this pass derived the same command as the first one did."""
+        self._captured = self.command
+        self.phase, self.action = "replay", action_row
+
     def get_action(self):
         if self.phase == "capture":
             raise StepSuspended()
         if self.phase == "replay" and self.action is not None:
+            # checked HERE, where the reference asks for the action (gym/robot_gym_env.py:121) and before the env applies
+            # anything: a step() whose pre-controller code is not repeatable must not reach ApplyStepAction
+            if self.command != self._captured:
+                raise RuntimeError(f"step() derived a different command on re-entry ({self.command} vs {self._captured}): its "
+                                   "pre-controller code is not repeatable -- give the env pre_step / post_step (robot_gym_amd/gym/split_step.py)")
             return np.array(self.action, dtype=np.float32)
         raise RuntimeError("BatchSlotController.get_action() outside MPCVecEnv.step(): this controller is one slot of a "
                            "batched GPU controller and has no action of its own (use MPCController for a single env)")

@@ -156,3 +156,16 @@ class SplitGoEnv(FakeGoEnv):
         if "update_equip" in kwargs:
             self.simulation.robot.update_equipment()
         return np.array(self.get_observation()), self.reward(), *self.termination()
+
+
+def make_fake_env(kind, robot, seed, batch, b, **kw):
+    """Picklable env constructor for MPCVecEnv(blocking=False): runs INSIDE a worker process (the reference's
+    ExternalProcess takes such a `constructor`, agents/ppo/tools/wrappers.py:306-327) and rebuilds the seeded synthetic
+    state there."""
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd import synthetic
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    cfg = MPCConfig.for_robot(robot)
+    state, _, _ = synthetic.make_states(batch, cfg, seed=seed)
+    cls = {"go": FakeGoEnv, "split": SplitGoEnv, "base": FakeRobotGymEnv}[kind]
+    return cls(cfg, state, b, BatchSlotController, **kw)

@@ -118,6 +118,7 @@ def run_gpu(cfg, state, cmd, t_off, ticks, dt=0.01, jitter=None, device="cuda:0"
             o[kx] = v.cpu().numpy().copy()
         o["bins"] = ctl.bin_counts()
         o["solver_stats"] = ctl.solver_stats()
+        o["iters"], o["stance_legs"] = ctl._handle.last_iterations(B, ctl._stream())
         outs.append(o)
     if outs:
         outs[-1]["audit"] = ctl.audit_stats()   # audit lane, cumulative over the run (waits for the side stream)

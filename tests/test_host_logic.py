@@ -206,6 +206,90 @@ def test_vec_env_host_logic_keeps_each_envs_own_step(monkeypatch):
     assert all(e.closed for e in envs) and ctl.closed
 
 
+def test_vec_env_worker_processes_match_the_in_process_path(monkeypatch):
+    """MPCVecEnv(blocking=False): the envs live in spawned worker processes (slices of the batch), phases 1 and 3 run there
+    in parallel, the state travels through ONE shared slab and the parent makes the one batched call -- the reference's
+    BatchEnv(envs, blocking=False) over ExternalProcess workers (batch_env.py:80-84, wrappers.py:294-458) with the
+    controller call cut out of the middle.  Same observations, same commands, clocks, resets and action rows as the
+    in-process path; attribute forwarding goes through the first worker; a worker-side exception is re-raised here."""
+    import functools
+    import torch
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd.gym import vec_env
+    from tests.fake_envs import make_fake_env, Box
+    monkeypatch.setattr(vec_env, "BatchedMPCController", _RecordingBatchedController)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    cfg = MPCConfig.for_robot("ghost")
+    B = 7
+    kinds = ["go", "split", "go", "split", "go", "go", "split"]
+    kw = [dict(on_target=(b == 1), follow_camera=(b == 4)) for b in range(B)]
+    ctors = [functools.partial(make_fake_env, kinds[b], "ghost", 3, B, b, **kw[b]) for b in range(B)]
+    par = vec_env.MPCVecEnv(blocking=False, constructors=ctors, workers=3, config=cfg)
+    ser = vec_env.MPCVecEnv([c() for c in ctors], config=cfg)
+    try:
+        assert len(par) == B and par.action_space == Box([-1, -1], [1, 1]) and par.closed is False   # `closed`: forwarded to env 0 in worker 0
+        np.testing.assert_array_equal(par.reset(), ser.reset())
+        rng = np.random.default_rng(5)
+        for k in range(4):
+            actions = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+            if k == 2:
+                np.testing.assert_array_equal(par.reset([0, 5]), ser.reset([0, 5]))
+            op, rp, dp, ip = par.step(actions)
+            os_, rs, ds, is_ = ser.step(actions)
+            np.testing.assert_array_equal(op, os_)
+            np.testing.assert_array_equal(rp, rs)
+            np.testing.assert_array_equal(dp, ds)
+            assert ip == is_
+            a, b_ = par.controller.calls[-1], ser.controller.calls[-1]
+            assert sorted(a) == sorted(b_)
+            for name in a:
+                assert torch.equal(a[name], b_[name]), name       # the same slab reached the one batched call
+        assert par.controller.resets == ser.controller.resets and par.batched_calls == 4
+        with pytest.raises(ValueError, match="Invalid action at index 3"):
+            par.step(np.array([[0, 0]] * 3 + [[2.0, 0]] + [[0, 0]] * 3, dtype=np.float32))
+        with pytest.raises(Exception, match="AttributeError"):
+            par.no_such_attribute
+    finally:
+        par.close()
+        ser.close()
+    assert par.controller.closed
+
+
+def test_vec_env_refuses_a_non_repeatable_step_before_anything_is_applied(monkeypatch):
+    """An env without pre_step / post_step is stepped twice per tick (capture + replay).  If its pre-controller code derives a
+    different command on the second pass, the slot controller refuses INSIDE get_action -- before ApplyStepAction -- and the
+    split-step mixin is the documented fix (one pass)."""
+    import torch
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd.gym import vec_env
+    from robot_gym_amd.gym.split_step import RobotGymEnvSplitStep
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    from tests.fake_envs import FakeRobotGymEnv
+    monkeypatch.setattr(vec_env, "BatchedMPCController", _RecordingBatchedController)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    cfg = MPCConfig.for_robot("ghost")
+    state, _, _ = synthetic.make_states(2, cfg, seed=3)
+
+    class Drifting(FakeRobotGymEnv):
+        def step(self, action, **kwargs):
+            self.calls = getattr(self, "calls", 0) + 1
+            return super().step((action[0] + 0.01 * self.calls, action[1], action[2]), **kwargs)   # not repeatable
+
+    envs = [Drifting(cfg, state, b, BatchSlotController) for b in range(2)]
+    venv = vec_env.MPCVecEnv(envs, config=cfg)
+    with pytest.raises(RuntimeError, match="not repeatable"):
+        venv.step(np.zeros((2, 3), dtype=np.float32))
+    assert all(len(e.simulation.applied) == 0 for e in envs)       # nothing reached ApplyStepAction
+
+    class Fixed(RobotGymEnvSplitStep, Drifting):                   # the mixin's halves of RobotGymEnv.step: one pass per tick
+        @property
+        def _simulation(self): return self.simulation
+    envs = [Fixed(cfg, state, b, BatchSlotController) for b in range(2)]
+    venv = vec_env.MPCVecEnv(envs, config=cfg)
+    obs, rew, done, info = venv.step(np.zeros((2, 3), dtype=np.float32))
+    assert obs.shape == (2, 2) and all(len(e.simulation.applied) == 1 and getattr(e, "calls", 0) == 0 for e in envs)
+
+
 def test_vec_env_matches_reference_batch_env_behaviour(monkeypatch):
     """MPCVecEnv against tests/golden/batch_env.json -- what the reference's own BatchEnv (agents/ppo/tools/batch_env.py:18-115,
     imported by tests/golden/make_golden.py) returned, forwarded and raised when driven with the same fake envs."""
