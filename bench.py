@@ -153,7 +153,7 @@ def with_f64_rate(view, dur_s):
     return view
 
 
-def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, schedule=False, ring=RING, amp=0.1):
+def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, schedule=False, ring=RING, amp=0.1, gpu_mean_iters=50.0):
     """Time the oracle (port) on the host cores on a bounded sample of the same workload: the first min(batch, 2048)
     robots of the same seeded batch, the same per-tick input variation, for as many ticks as fit the budget."""
     from oracle import oracle as O
@@ -202,8 +202,36 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
         el = time.perf_counter() - t0
         if el > budget_s or ticks >= 2000:
             break
-    return {"value": Bs * ticks / el, "unit": "controller steps/s", "cores": cores, "kind": "port",
-            "sample": f"{Bs} robots x {ticks} ticks of this workload (seed 0, same per-tick input variation), float64 C oracle with exact active-set QP, OpenMP over robots"}
+    out = {"value": Bs * ticks / el, "unit": "controller steps/s", "cores": cores, "kind": "port",
+           "sample": f"{Bs} robots x {ticks} ticks of this workload (seed 0, same per-tick input variation), float64 C oracle with exact active-set QP, OpenMP over robots"}
+
+    def timed(nthreads, budget):
+        ob2 = fresh(nthreads)
+        ob2.step(0.0, inputs[0])
+        t1, n = time.perf_counter(), 0
+        while True:
+            ob2.step(0.01 * (n + 1), inputs[(n + 1) % len(inputs)])
+            n += 1
+            e2 = time.perf_counter() - t1
+            if e2 > budget or n >= 500:
+                return Bs * n / e2, n
+
+    # BASELINE.md section 2 variants, bounded samples of the same inputs (a few seconds each):
+    #   B0  one thread, a plain loop over robots -- the shape of the reference's CPU path (one Python controller object per env,
+    #       reference controllers/mpc/mpc_controller.py:102-106 called from gym/robot_gym_env.py:120-121), minus the interpreter
+    #   B1  every host core, the SAME over-relaxed ADMM as the GPU kernels at the GPU's mean iteration count (dense Cholesky
+    #       of P + rho I, two triangular solves and the pyramid projection per iteration) instead of the exact solver
+    try:
+        v0, n0 = timed(1, 3.0)
+        O.set_qp_mode(1, max(1, int(round(gpu_mean_iters))), cfg.admm_rho, cfg.admm_relax)
+        all_cores = (os.cpu_count() or 1) if Bs >= 64 else 1
+        v1, n1 = timed(all_cores, 3.0)
+        out["variants"] = {"B0_one_thread_exact_qp": {"value": v0, "cores": 1, "sample": f"{Bs} robots x {n0} ticks"},
+                           "B1_all_cores_fixed_count_admm": {"value": v1, "cores": all_cores, "admm_iterations": int(round(gpu_mean_iters)),
+                                                             "sample": f"{Bs} robots x {n1} ticks, rho {cfg.admm_rho} relax {cfg.admm_relax}"}}
+    finally:
+        O.set_qp_mode(0)
+    return out
 
 
 def self_launch(args, argv):
@@ -525,7 +553,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not dry:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, B, fixed_cmd=fixed_cmd, gait_seed=(0 if args.random_schedule else None),
-                                                   schedule=args.random_schedule, ring=ring, amp=args.jitter)
+                                                   schedule=args.random_schedule, ring=ring, amp=args.jitter,
+                                                   gpu_mean_iters=stats.get("iters_mean", 50.0))
             except Exception as e:  # the baseline is a reported extra, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "controller steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)

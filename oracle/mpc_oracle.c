@@ -494,9 +494,57 @@ static int gi_add(int n, double *R, double *J, double *d, int *iq, double *rnorm
   return 1;
 }
 
+/* ---- CPU-baseline variant B1: the SAME over-relaxed ADMM as the GPU kernels, a fixed number of
+ * iterations, dense linear algebra: Cholesky of P + rho I once, then two triangular solves and the exact pyramid projection
+ * per iteration.  Selected process-wide by orc_set_qp_mode(1, ...); used only by bench.py's cpu_baseline variants -- the parity
+ * oracle is the exact solver below (mode 0, the default). */
+static int g_qp_mode = 0, g_admm_iters = 50;
+static double g_admm_rho = 1e-4, g_admm_relax = 1.8;
+void orc_set_qp_mode(int mode, int admm_iters, double rho, double relax) { g_qp_mode = mode; g_admm_iters = admm_iters; g_admm_rho = rho; g_admm_relax = relax; }
+
+/* Euclidean projection of (a, b, c) onto { |x| <= mu z, |y| <= mu z, lo <= z <= hi } */
+static void project_pyramid(double a, double b, double c, double mu, double lo, double hi, double *o) {
+  double aa = fabs(a), bb = fabs(b), mn = aa < bb ? aa : bb, mx = aa < bb ? bb : aa;
+  double zA = (c + mu * (aa + bb)) / (1.0 + 2.0 * mu * mu), zB = (c + mu * mx) / (1.0 + mu * mu);
+  double z = (mu * zA < mn) ? zA : ((mu * zB < mx) ? zB : c);
+  z = z < lo ? lo : (z > hi ? hi : z);
+  double lim = mu * z;
+  o[0] = a < -lim ? -lim : (a > lim ? lim : a);
+  o[1] = b < -lim ? -lim : (b > lim ? lim : b);
+  o[2] = z;
+}
+
+static int qp_admm_fixed(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x) {
+  const int nb = n / 3;
+  double *L = malloc(sizeof(double) * n * n), *z = calloc(n, sizeof(double)), *y = calloc(n, sizeof(double)), *u = malloc(sizeof(double) * n);
+  for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) L[i * n + j] = P[i * n + j] + (i == j ? g_admm_rho : 0.0);
+  for (int j = 0; j < n; j++) {
+    double s = L[j * n + j];
+    for (int k = 0; k < j; k++) s -= L[j * n + k] * L[j * n + k];
+    if (!(s > 0)) { free(L); free(z); free(y); free(u); return -1; }
+    double d = sqrt(s); L[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) { double t = L[i * n + j]; for (int k = 0; k < j; k++) t -= L[i * n + k] * L[j * n + k]; L[i * n + j] = t / d; }
+  }
+  for (int b = 0; b < nb; b++) z[3 * b + 2] = fz_lo;
+  for (int it = 0; it < g_admm_iters; it++) {
+    for (int i = 0; i < n; i++) { double t = g_admm_rho * (z[i] - y[i]) - qv[i]; for (int k = 0; k < i; k++) t -= L[i * n + k] * u[k]; u[i] = t / L[i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double t = u[i]; for (int k = i + 1; k < n; k++) t -= L[k * n + i] * u[k]; u[i] = t / L[i * n + i]; }
+    for (int b = 0; b < nb; b++) {
+      double w[3], pz[3];
+      for (int a = 0; a < 3; a++) w[a] = g_admm_relax * u[3 * b + a] + (1.0 - g_admm_relax) * z[3 * b + a] + y[3 * b + a];
+      project_pyramid(w[0], w[1], w[2], mu_blk[b], fz_lo, fz_hi, pz);
+      for (int a = 0; a < 3; a++) { y[3 * b + a] = w[a] - pz[a]; z[3 * b + a] = pz[a]; }
+    }
+  }
+  memcpy(x, z, sizeof(double) * n);
+  free(L); free(z); free(y); free(u);
+  return g_admm_iters;
+}
+
 int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]) {
   const int nb = n / 3, m = 6 * nb;
   if (n == 0) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; return 0; }
+  if (g_qp_mode == 1) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; return qp_admm_fixed(n, P, qv, mu_blk, fz_lo, fz_hi, x); }
   double *L = malloc(sizeof(double) * n * n), *J = calloc((size_t)n * n, sizeof(double)), *R = calloc((size_t)n * n, sizeof(double));
   double *d = malloc(sizeof(double) * n), *z = malloc(sizeof(double) * n), *r = malloc(sizeof(double) * n);
   double *u = calloc((size_t)m + 1, sizeof(double)), *s = malloc(sizeof(double) * m);

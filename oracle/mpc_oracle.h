@@ -148,6 +148,10 @@ void orc_gait_desired(const orc_config *c, double t, int desired[4]);
 int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk /* n/3 */, double fz_min, double fz_max,
                  double *u, double kkt[3]);
 
+/* bench.py's cpu_baseline variant B1 only: mode 1 = the same over-relaxed ADMM as the GPU kernels with a FIXED iteration
+ * count and dense linear algebra instead of the exact solver (process-wide; mode 0 = exact, the default and the parity oracle) */
+void orc_set_qp_mode(int mode, int admm_iters, double rho, double relax);
+
 /* batch helpers (OpenMP over robots) */
 int orc_step_batch(const orc_config *c, orc_state *s, int B, double t_now, const orc_input *in, orc_output *out, int nthreads);
 /* same with one config per robot (per-robot gait timing: BASELINE config 5 draws a random duty factor per robot) */

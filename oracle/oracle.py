@@ -84,6 +84,8 @@ def lib():
         L.orc_reset.argtypes = [C.POINTER(Config), C.POINTER(State), d, C.c_void_p]
         L.orc_step.argtypes = [C.POINTER(Config), C.POINTER(State), d, C.POINTER(Input), C.POINTER(Output)]
         L.orc_step.restype = i32
+        L.orc_set_qp_mode.argtypes = [i32, i32, d, d]
+        L.orc_set_qp_mode.restype = None
         L.orc_step_batch.argtypes = [C.POINTER(Config), C.c_void_p, i32, d, C.c_void_p, C.c_void_p, i32]
         L.orc_step_batch.restype = i32
         L.orc_step_batch_cfgs.argtypes = [C.c_void_p, C.c_void_p, i32, d, C.c_void_p, C.c_void_p, i32]
@@ -205,3 +207,9 @@ def qp_solve(P, q, mu, fz_min, fz_max):
     kkt = np.zeros(3)
     it = lib().orc_qp_solve(n, _p(P), _p(q), _p(mu_blk), fz_min, fz_max, _p(u), _p(kkt))
     return u, it, kkt
+
+
+def set_qp_mode(mode=0, admm_iters=50, rho=1e-4, relax=1.8):
+    """Process-wide QP solver of the oracle: 0 = exact dual active set (the parity oracle), 1 = fixed-count ADMM with dense
+    linear algebra (bench.py's cpu_baseline variant B1 only)."""
+    lib().orc_set_qp_mode(int(mode), int(admm_iters), float(rho), float(relax))

@@ -32,6 +32,12 @@ for r in range(rounds):
                 w = m["tau_rel_argmax"]
                 print(f"PARITY MISS round {r} seed {s} tick {k}: robot {w} of {B}: stance legs {g['stance_legs'][w]} iterations {g['iters'][w]} desired {g['desired_state'][w].tolist()} "
                       f"leg_state {g['leg_state'][w].tolist()} tau_rel {m['tau_rel_max']:.3e}; iterations of all robots {g['iters'].tolist()}", flush=True)
+                print("   grf gpu   ", np.round(g["grf"][w].astype(np.float64), 4).tolist())
+                print("   grf oracle", np.round(np.asarray(o["grf"][w], dtype=np.float64), 4).tolist())
+                print("   foot_target gpu", np.round(g["foot_target"][w], 5).tolist(), "v_body", g["v_body"][w].tolist())
+                again = helpers.run_gpu(cfg, **kw)[k]
+                m2 = helpers.compare_tick(again, o)
+                print(f"   same configuration again in this process: tau_rel {m2['tau_rel_max']:.3e}; grf of the robot {np.round(again['grf'][w].astype(np.float64), 4).tolist()}", flush=True)
             if not np.array_equal(a, a0) or m["tau_rel_max"] > 1e-4:
                 bad += 1
                 d = np.abs(a.astype(np.float64) - a0.astype(np.float64)).reshape(B, -1).max(1)
