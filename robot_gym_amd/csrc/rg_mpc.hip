@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -114,6 +115,44 @@ struct DeviceScope {
 };
 
 static thread_local std::string g_create_err;
+
+// The audit lane's side stream and its events come from a per-device pool and go back to it when a handle is destroyed;
+// they are never handed to hipStreamDestroy / hipEventDestroy.  Destroying them corrupted the HOST heap of the process under
+// ROCm 7.2: in ~7 % of fresh processes that create and destroy a few handles, some 100 ms after rg_mpc_destroy a 32-bit word
+// of a recycled ~900-byte heap block is decremented by one and another one zeroed -- a reference count released and a field
+// cleared by the runtime in an object it had already freed (tests/studies/host_corruption_hunt.py caught it as a changed
+// element of a numpy input array: a parity "failure" of a robot whose quaternion had lost its w component; with audit_k = 0,
+// i.e. without these streams and events, 0 of 60 processes).  A stream with cross-stream event waits behind it seems to be
+// what the runtime mishandles; recycling the objects sidesteps it and saves their creation cost per handle.
+struct AuditLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t fused[RG_AUDIT_RING] = {}, done[RG_AUDIT_RING] = {};
+};
+static std::mutex g_lane_mu;
+static std::vector<AuditLane> g_lane_pool[64];   // per device
+
+static hipError_t audit_lane_acquire(int device, AuditLane *lane) {
+  {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    if (device >= 0 && device < 64 && !g_lane_pool[device].empty()) { *lane = g_lane_pool[device].back(); g_lane_pool[device].pop_back(); return hipSuccess; }
+  }
+  // lowest priority: the exact re-solves fill the gaps the tick's own launches leave (the tail of the ADMM launch), they must
+  // not compete with them for CUs
+  int prio_low = 0, prio_high = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio_low);
+  for (int k = 0; k < RG_AUDIT_RING && e == hipSuccess; k++) {
+    e = hipEventCreateWithFlags(&lane->fused[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&lane->done[k], hipEventDisableTiming);
+  }
+  return e;
+}
+static void audit_lane_release(int device, const AuditLane &lane) {
+  if (!lane.stream) return;
+  (void)hipStreamSynchronize(lane.stream);
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  if (device >= 0 && device < 64) g_lane_pool[device].push_back(lane);
+}
 
 #define RG_PROF_EV 11  // [0] step start, [1] front end, [2+2k],[3+2k] QP nc=k+1 start/end, [10] step end
 #define HIPCHK(h, call)                                                                    \
@@ -265,17 +304,10 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   if (h->audit_on) {
     AL(h->st.audit_rec, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * RG_REC_N); AL(h->st.audit_f, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * 12);
     AL(h->st.audit_idx, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS); AL(h->st.audit_cnt, RG_AUDIT_RING); AL(h->st.audit_stat, 8);
-    {
-      // lowest priority: the exact re-solves fill the gaps the tick's own launches leave (the tail of the ADMM launch), they
-      // must not compete with them for CUs
-      int prio_low = 0, prio_high = 0;
-      CR(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-      CR(hipStreamCreateWithPriority(&h->audit_stream, hipStreamNonBlocking, prio_low));
-    }
-    for (int k = 0; k < RG_AUDIT_RING; k++) {
-      CR(hipEventCreateWithFlags(&h->audit_fused[k], hipEventDisableTiming));
-      CR(hipEventCreateWithFlags(&h->audit_done[k], hipEventDisableTiming));
-    }
+    AuditLane lane;
+    CR(audit_lane_acquire(device, &lane));
+    h->audit_stream = lane.stream;
+    for (int k = 0; k < RG_AUDIT_RING; k++) { h->audit_fused[k] = lane.fused[k]; h->audit_done[k] = lane.done[k]; }
   }
 #undef CR
 #undef AL
@@ -293,12 +325,12 @@ void rg_mpc_destroy(rg_mpc_handle *h) {
   if (!h) return;
   {
     DeviceScope dev_(h->device);
-    if (h->audit_stream) (void)hipStreamSynchronize(h->audit_stream);
-    for (int k = 0; k < RG_AUDIT_RING; k++) {
-      if (h->audit_fused[k]) (void)hipEventDestroy(h->audit_fused[k]);
-      if (h->audit_done[k]) (void)hipEventDestroy(h->audit_done[k]);
+    if (h->audit_stream) {   // back to the pool, not destroyed (see AuditLane)
+      AuditLane lane;
+      lane.stream = h->audit_stream;
+      for (int k = 0; k < RG_AUDIT_RING; k++) { lane.fused[k] = h->audit_fused[k]; lane.done[k] = h->audit_done[k]; }
+      audit_lane_release(h->device, lane);
     }
-    if (h->audit_stream) (void)hipStreamDestroy(h->audit_stream);
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   }

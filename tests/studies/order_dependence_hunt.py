@@ -35,6 +35,19 @@ for r in range(rounds):
                 print("   grf gpu   ", np.round(g["grf"][w].astype(np.float64), 4).tolist())
                 print("   grf oracle", np.round(np.asarray(o["grf"][w], dtype=np.float64), 4).tolist())
                 print("   foot_target gpu", np.round(g["foot_target"][w], 5).tolist(), "v_body", g["v_body"][w].tolist())
+                print("   v_body oracle", np.asarray(o["v_body"][w]).tolist(), "audit", gpu[-1]["audit"], "oracle kkt", np.asarray(o["kkt"][w]).tolist())
+                dv = np.abs(g["v_body"].astype(np.float64) - np.asarray(o["v_body"])).max(1)
+                print("   robots whose filtered body velocity differs from the oracle's by > 1e-6:", np.nonzero(dv > 1e-6)[0].tolist(), "max", dv.max())
+                st0 = helpers.perturb(kw["state"], k, kw["jitter"])
+                print("   robot inputs: v_world", st0["v_world"][:, w].tolist(), "quat", st0["quat"][:, w].tolist(), "rpy", st0["rpy"][:, w].tolist(), "window", cfg.window, "t_off", float(kw["t_off"][w]))
+                import dataclasses
+                for label, c2 in (("exact GPU solver (RG_SOLVER_ACTIVE_SET)", dataclasses.replace(cfg, solver=1)), ("audit_k = 0", dataclasses.replace(cfg, audit_k=0)),
+                                  ("admm_accel = 0", dataclasses.replace(cfg, admm_accel=0)), ("admm_tol 1e-8", dataclasses.replace(cfg, admm_tol=1e-8))):
+                    try:
+                        g2 = helpers.run_gpu(c2, **kw)[k]
+                        print(f"   {label}: tau_rel {helpers.compare_tick(g2, o)['tau_rel_max']:.3e} iterations {g2['iters'][w]} grf {np.round(g2['grf'][w].astype(np.float64), 4).tolist()}", flush=True)
+                    except Exception as e:
+                        print(f"   {label}: {type(e).__name__}: {e}")
                 again = helpers.run_gpu(cfg, **kw)[k]
                 m2 = helpers.compare_tick(again, o)
                 print(f"   same configuration again in this process: tau_rel {m2['tau_rel_max']:.3e}; grf of the robot {np.round(again['grf'][w].astype(np.float64), 4).tolist()}", flush=True)
