@@ -4,8 +4,9 @@
 // Each 256-lane workgroup votes in a loop the way the ADMM bodies do: per vote one lane (a different wave each time) says
 // "still moving" until its own stopping iteration; every wave records the vote results it saw and the iteration at which it
 // left the loop.  A correct workgroup reduction gives every wave the same record.  Between repetitions a second kernel with
-// a large unrolled body evicts the instruction cache, and the workgroups do a data-dependent amount of LDS / VALU work
-// between votes so that their waves arrive at the vote at different times.  Variant 0: the device library's
+// a large unrolled body evicts the instruction cache, every other repetition a third kernel leaves all LDS full of a non-zero
+// pattern, and the workgroups do a data-dependent amount of LDS / VALU work between votes so that their waves arrive at the
+// vote at different times.  Variant 0: the device library's
 // __syncthreads_or.  Variant 1: ballot + LDS flags + two barriers (what the library uses now).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -19,6 +20,16 @@ __global__ void evict_icache(double *out, int n) {   // ~70 KB of straight-line 
     for (int k = 0; k < 4096; k++) { a = fma(a, 1.0000001, b); b = fma(b, 0.9999999, a * 1e-9 + k); }
   }
   if (a == 12345.678) out[0] = a + b;
+}
+
+// LDS keeps its contents from kernel to kernel: leave every CU's LDS full of a non-zero pattern before the vote kernel, the
+// way another QP kernel (or the test suite's poison kernel) does -- a workgroup reduction that expected its LDS accumulator to
+// start at zero would now start from garbage.
+extern __shared__ unsigned dyn_lds[];
+__global__ void fill_lds(unsigned pattern, int nwords) {
+  for (int e = threadIdx.x; e < nwords; e += blockDim.x) dyn_lds[e] = pattern;
+  __syncthreads();
+  if (dyn_lds[(threadIdx.x * 7) % nwords] == 1u) dyn_lds[0] = 2u;
 }
 
 __shared__ int slots[16];
@@ -64,6 +75,7 @@ static long run(int reps, int wgs) {
   long bad = 0;
   for (int r = 0; r < reps; r++) {
     evict_icache<<<1024, 64>>>(d_out, 2);
+    if (r & 1) fill_lds<<<2048, 256, 64 * 1024>>>((r & 2) ? 0xFFFFFFFFu : 0x7ff8deadu, 16 * 1024);   // odd repetitions: dirty LDS first
     vote_loop<VARIANT><<<wgs, 256>>>(d_exit, d_seen, 48, 1234567u * (r + 1));
     hipMemcpy(ex.data(), d_exit, ex.size() * sizeof(int), hipMemcpyDeviceToHost);
     hipMemcpy(sn.data(), d_seen, sn.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);

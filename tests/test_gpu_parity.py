@@ -389,10 +389,11 @@ def test_randomised_configurations(oracle_lib, seed):
 def test_launch_order_independence(oracle_lib):
     """The same configuration gives the same commands (to 1e-5, a tenth of the tolerance) whatever ran on the device before it.
     Found necessary when a build of the horizon-20 fused launch was right on a fresh device and wrong (forces 10-30 % off
-    for its three-leg robots, not NaN, every counter clean) once any other QP kernel had run in the process.  Root cause:
-    __syncthreads_or gave one wave of a 256-lane workgroup a different vote result than the others when the launch's
-    timing shifted (cold instruction cache); that wave left the ADMM loop at its first vote.  workgroup_any
-    (rg_qp_common.inc) no longer uses it; this test fails on the old one.  Sequence: horizon 20 constant contacts (fused
+    for its three-leg robots, not NaN, every counter clean) once any other QP kernel had run in the process: one wave of
+    the 256-lane workgroup had left the ADMM loop at its first vote.  The vote was __syncthreads_or then; with workgroup_any
+    (rg_qp_common.inc: ballot, LDS flags, a barrier on either side) the failure does not occur and this test, which fails on
+    the old code, guards it.  (That the library primitive itself misbehaves is not confirmed: tests/studies/
+    syncthreads_or_repro.hip does not reproduce it stand-alone.)  Sequence: horizon 20 constant contacts (fused
     launch, 256 lanes), horizon 10 gait schedule (schedule kernel), horizon 20 caller schedule, horizon 10 constant
     contacts, then all of them again in another order."""
     cases = {s: _sweep_case(s) for s in (9, 0, 1, 3, 12, 2)}     # (H20 fused) (H10 sched) (H20 sched) (H10 fused) (H20 fused) (H20 sched, warm)
