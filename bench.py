@@ -519,6 +519,11 @@ def main():
             wl, wkey = f"batch={B} quadrupeds per GPU, horizon={args.horizon}{' with gait-driven contact schedule' if args.lookahead else ''}, randomised (vx,vy,wz) commands (BASELINE configs[2])", ("headline" if args.horizon == HORIZON and not args.lookahead else f"h{args.horizon}{'la' if args.lookahead else ''}")
             if B != BATCH_PER_GPU:
                 wkey = f"b{B}" if wkey == "headline" else f"{wkey}_b{B}"
+        if args.kin_mode:
+            wl += f", kin_mode {args.kin_mode} (foot positions, Jacobians and IK from joint angles on the device)"
+            wkey = f"kin{args.kin_mode}" if wkey == "headline" else f"{wkey}_kin{args.kin_mode}"
+        if args.random_schedule and args.cap is not None:
+            wkey = f"config5_cap{args.cap}"
         prof = load_profile(B, wkey)
         audit = stats.pop("audit", None)
         out = {

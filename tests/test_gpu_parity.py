@@ -537,3 +537,19 @@ def test_audit_lane_notices_a_sloppy_exit_and_never_touches_outputs():
     ctl.close()
     assert a["audited"] >= 50 and a["audit_over_tol"] > 0 and a["audit_max_rel"] > 1e-4, a
     print("sloppy exit seen by the audit:", a)
+
+
+def test_strict_per_joint_reading_is_met_at_admm_tol_1e_7(oracle_lib):
+    """north_star: "torques within 1e-4 rel of the CPU reference".  The library default (admm_tol 1e-6) meets it per robot --
+    max_j |dtau_j| / max(max_j |tau_j|, 1 N m) -- with 3-5x margin; read per joint, |dtau_j| / max(|tau_j|, 1 N m), a small joint
+    torque next to a large one carries the large one's absolute error and the default reaches 3e-4.  profiles/
+    r3_tolerance_table.md has the curve; this pins its strict end: admm_tol = 1e-7 (6.5 % slower on the headline bench) keeps
+    every JOINT within 1e-4 as well."""
+    cfg = MPCConfig.for_robot("ghost", admm_tol=1e-7)
+    state, cmd, t_off = synthetic.make_states(1024, cfg, seed=0)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=8, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=8, jitter=0.1, poison=False)
+    worst = max(helpers.compare_tick(g, o)["tau_rel_elem_max"] for g, o in zip(gpu, orc))
+    assert worst <= TORQUE_REL_TOL, worst
+    helpers.assert_audit_clean(gpu[-1]["audit"])
+    assert gpu[-1]["audit"]["audit_max_rel_elem"] <= TORQUE_REL_TOL

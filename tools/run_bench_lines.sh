@@ -3,10 +3,13 @@
 # BASELINE workload, now carrying the profile-derived fields (roofline.traffic, roofline.issue_view).  -> gpurun_out/bench_<key>.json
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p gpurun_out
 run() { local key=$1; shift; python3 bench.py --steps 20 --warmup 5 "$@" > gpurun_out/bench_$key.json 2> gpurun_out/bench_$key.err; echo "$key: $(python3 -c "import json;d=json.loads(open('gpurun_out/bench_$key.json').read());print(round(d['value']/1e6,3),'M steps/s', d['roofline']['kernel_ms'], 'traffic', d['roofline']['traffic'])")"; }
 run headline
 run config2 --batch 1024 --fixed-cmd
 run b1 --batch 1
 run h20 --horizon 20
-run config5 --horizon 20 --random-schedule --cap 600
+run config5 --horizon 20 --random-schedule
+run config5_cap600 --horizon 20 --random-schedule --cap 600
 run b32768 --batch 32768
+run kin1 --kin-mode 1

@@ -9,7 +9,7 @@ so the raw value is reported and the 2x-corrected value is given as an upper bou
 import collections, csv, glob, json, os, shutil, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"       # r2 (headline) or r2_<workload key>: bench.py profile_tag()
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"       # r3 (headline) or r3_<workload key>: bench.py profile_tag()
 workload_key = tag.split("_", 1)[1] if "_" in tag else "headline"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
