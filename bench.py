@@ -58,14 +58,35 @@ def perturb_state(state, k, amp):
     return st
 
 
-def make_input_ring(cfg, B, seed, device, ring, amp, fixed_cmd=None, gait=None, schedule=False):
+def chain_geometry(cfg, state):
+    """foot_pos / jac of a synthetic batch replaced by the URDF chain's forward kinematics of its joint angles (host twin of
+    the device code, controllers/mpc/kinematics.ChainKinematics): what kin_mode 1 computes on the device, handed to kin_mode 0
+    as inputs -- both modes then solve the same QPs and their difference is the cost of the on-device kinematics."""
+    from robot_gym_amd.controllers.mpc.kinematics import ChainKinematics
+    ck = ChainKinematics(cfg)
+    B = state["q"].shape[1]
+    q = state["q"].astype(np.float64)
+    foot, jac = np.zeros((4, 3, B)), np.zeros((4, 3, 3, B))
+    for b in range(B):
+        for leg in range(4):
+            foot[leg, :, b], jac[leg, :, :, b] = ck.foot_position_and_jacobian(leg, q[3 * leg:3 * leg + 3, b])
+    state = dict(state)
+    state["foot_pos"], state["jac"] = foot.reshape(12, B).astype(np.float32), jac.reshape(36, B).astype(np.float32)
+    return state
+
+
+def make_input_ring(cfg, B, seed, device, ring, amp, fixed_cmd=None, gait=None, schedule=False, chain_geom=False):
     """`ring` input slabs on the device: slab j is the state handed to tick k = j (mod ring)."""
     from robot_gym_amd import synthetic
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed, fixed_cmd=fixed_cmd)
+    if chain_geom:
+        state = chain_geometry(cfg, state)
     names = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")
     slabs = []
     for j in range(ring):
         st = perturb_state(state, j, amp) if ring > 1 else state
+        if chain_geom:
+            st["foot_pos"] = state["foot_pos"]   # the feet follow the joint angles, which the ring does not vary
         dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).to(device) for n in names}
         dev["contact"] = torch.from_numpy(synthetic.gait_consistent_contacts(cfg, t_off + 0.01 * j, state["_flip"], gait)).to(device)
         if schedule:   # BASELINE config 5: randomised per-step contact schedule, re-drawn every tick
@@ -305,6 +326,7 @@ def main():
     ap.add_argument("--dry-launch", action="store_true", help="CPU dry run of the multi-rank protocol: gloo, a stub controller, no GPU")
     ap.add_argument("--force-launcher", action="store_true", help="start the ranks through self_launch even for --gpus 1 (tests the launcher on a 1-GPU box)")
     ap.add_argument("--kin-mode", type=int, default=0, help="1 = foot positions / Jacobians from joint angles on the device (chain kinematics replacing controllers/mpc/kinematics.py)")
+    ap.add_argument("--chain-geometry", action="store_true", help="synthetic foot positions / Jacobians = forward kinematics of the synthetic joint angles (what kin_mode 1 computes on the device), so that --kin-mode 0 and 1 solve the same QPs")
     ap.add_argument("--robot", default="ghost")
     ap.add_argument("--audit-k", type=int, default=None, help="audit lane picks per tick (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -393,7 +415,7 @@ def main():
     fixed_cmd = (0.3, 0.0, 0.0) if args.fixed_cmd else None
     # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard
     gait = synthetic.random_gaits(B, cfg, seed=rank) if args.random_schedule else None
-    state, cmd, t_off, slabs = make_input_ring(cfg, B, rank, device, ring, args.jitter, fixed_cmd, gait, args.random_schedule)
+    state, cmd, t_off, slabs = make_input_ring(cfg, B, rank, device, ring, args.jitter, fixed_cmd, gait, args.random_schedule, args.chain_geometry)
     gathered = torch.empty(world * B, 60, dtype=torch.float32, device=device) if dist is not None else None
 
     def run(slab_list, steps, warmup, events, cfg_run=None, allgather=False):
@@ -522,6 +544,9 @@ def main():
         if args.kin_mode:
             wl += f", kin_mode {args.kin_mode} (foot positions, Jacobians and IK from joint angles on the device)"
             wkey = f"kin{args.kin_mode}" if wkey == "headline" else f"{wkey}_kin{args.kin_mode}"
+        if args.chain_geometry and not args.kin_mode:
+            wl += ", foot positions / Jacobians = chain forward kinematics of the joint angles (the geometry kin_mode 1 computes)"
+            wkey = "kin0chain" if wkey == "headline" else f"{wkey}_kin0chain"
         if args.random_schedule and args.cap is not None:
             wkey = f"config5_cap{args.cap}"
         prof = load_profile(B, wkey)

@@ -13,3 +13,8 @@ run config5 --horizon 20 --random-schedule
 run config5_cap600 --horizon 20 --random-schedule --cap 600
 run b32768 --batch 32768
 run kin1 --kin-mode 1
+# the geometry kin_mode 1 computes on the device (chain forward kinematics of the synthetic joint angles) handed to kin_mode 0
+# as inputs: the same QPs as the kin1 line, so the difference between the two is the cost of the on-device kinematics
+tools/collect_profiles.sh r3_kin0chain stats --chain-geometry > gpurun_out/collect_kin0chain.log 2>&1
+run kin0chain --chain-geometry
+python3 tools/vec_env_bench.py 20 > gpurun_out/r3_vec_env_host.txt 2> gpurun_out/r3_vec_env_host.err; cat gpurun_out/r3_vec_env_host.txt
