@@ -180,7 +180,10 @@ def _worker_main(conn, constructors, lo, batch, shm_state, shm_act, cfg, jacobia
                 message, _ = conn.recv()
                 if message != _ACT:
                     raise KeyError(f"expected the action message, got {message}")
-                conn.send((_TRANSITION, group.post(actions, act[lo:lo + len(envs)])))
+                # one message of stacked arrays per slice, not n pickled tuples (the parent's serial unpickling of 4096 small
+                # objects was most of the tick)
+                observs, rewards, dones, infos = zip(*group.post(actions, act[lo:lo + len(envs)]))
+                conn.send((_TRANSITION, (np.stack(observs), np.stack(rewards), np.stack(dones), list(infos))))
             elif message == _RESET:
                 conn.send((_OBSERV, group.reset(payload)))
             elif message == _ATTRIBUTE:
@@ -336,14 +339,22 @@ class MPCVecEnv:
             rows = self._controller_call(self._group.gather())
             transitions = self._group.post(actions, rows)
         else:
+            try:
+                batch_actions = np.asarray(actions)          # one contiguous block per worker instead of n small pickles
+                if batch_actions.dtype == object or batch_actions.shape[0] != self._batch:
+                    batch_actions = None
+            except ValueError:
+                batch_actions = None
             for w in self._workers:   # phase 1 of every slice runs concurrently
-                w.conn.send((_STEP, [actions[i] for i in range(w.lo, w.lo + w.n)]))
+                w.conn.send((_STEP, batch_actions[w.lo:w.lo + w.n] if batch_actions is not None else [actions[i] for i in range(w.lo, w.lo + w.n)]))
             resets = [r for w in self._workers for r in w.receive(_READY)]
             self._state.host_slab.numpy()[:] = self._shared_slab   # shared slab -> pinned slab (1.3 MB at B = 4096)
             self._shared_act[:] = self._controller_call(resets)
             for w in self._workers:   # ... and phase 3
                 w.conn.send((_ACT, None))
-            transitions = [t for w in self._workers for t in w.receive(_TRANSITION)]
+            parts = [w.receive(_TRANSITION) for w in self._workers]
+            return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]),
+                    tuple(i for p in parts for i in p[3]))
         observs, rewards, dones, infos = zip(*transitions)
         return np.stack(observs), np.stack(rewards), np.stack(dones), tuple(infos)
 
