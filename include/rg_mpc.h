@@ -226,12 +226,21 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
 
 /* Solver statistics of the last step (synchronises the stream): sum and max of solver iterations
  * (ADMM iterations / active-set constraint additions) over the robots that had a QP, the number of
- * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO) and how many solves failed
+ * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO: by ADMM at the iteration cap, or directly by the front
+ * kernel, see rg_mpc_last_direct_count) and how many solves failed
  * (robots with a non-finite input or an out-of-range gait row -- counted once, given an all-zero command row and
  * left out of the QP --, active-set breakdowns (incl. more than 160 active constraints in the wrench-space exact pass),
  * plus, under RG_SOLVER_ADMM only, robots ADMM left unconverged). */
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);
+
+/* Direct routing (horizon 10, constant contacts, RG_SOLVER_AUTO): a robot whose QP the exact solver had to take over is, while
+ * its contact set stays the same, sent straight to the exact solver by the following ticks instead of running ADMM to the
+ * iteration cap again (every 16th tick it tries ADMM again); when a recent tick had exact solves, those of the direct robots run
+ * in a launch of their own next to the ADMM launch.  direct_robots: robots solved that way in the last step (they are included
+ * in rg_mpc_last_solver_stats().retried); concurrent_launches: ticks so far that used the concurrent launch.
+ * Synchronises the stream. */
+int rg_mpc_last_direct_count(rg_mpc_handle *h, int32_t *direct_robots, int64_t *concurrent_launches, void *stream);
 
 /* Audit lane statistics, cumulative since create (or since the last call with reset != 0).  Waits for the audit work
  * in flight (library side stream) and for `stream`.  audited: robots re-solved exactly next to their converged ADMM

@@ -52,7 +52,7 @@ class COutPtrs(C.Structure):
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_set_gait", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
            "rg_mpc_hybrid_to_torque_substeps",
-           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_audit_stats", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_audit_stats", "rg_mpc_last_direct_count", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -91,6 +91,8 @@ def load_library(path=None):
     L.rg_mpc_audit_stats.argtypes = [fp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(d), C.POINTER(d), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_int64), i32, fp]
     L.rg_mpc_audit_stats.restype = i32
+    L.rg_mpc_last_direct_count.argtypes = [fp, C.POINTER(i32), C.POINTER(C.c_int64), fp]
+    L.rg_mpc_last_direct_count.restype = i32
     L.rg_mpc_profile_begin.argtypes = [fp, i32]
     L.rg_mpc_profile_begin.restype = i32
     L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
@@ -204,6 +206,13 @@ class MpcHandle:
                                                  1 if reset else 0, stream))
         return {"audited": a.value, "audit_over_tol": o.value, "audit_max_rel": mr.value, "audit_max_rel_elem": me.value,
                 "audit_exact_failures": f_.value, "audit_dropped": dr.value}
+
+    def last_direct_count(self, stream=None):
+        """(robots the front kernel sent straight to the exact solver in the last step, ticks so far whose direct lists ran in
+        a launch of their own next to the ADMM launch)."""
+        n, k = i32(), C.c_int64()
+        self._check(self._lib.rg_mpc_last_direct_count(self._h, C.byref(n), C.byref(k), stream))
+        return n.value, k.value
 
     def profile_begin(self, max_steps):
         self._check(self._lib.rg_mpc_profile_begin(self._h, int(max_steps)))

@@ -98,6 +98,11 @@ struct rg_mpc_handle {
   hipEvent_t audit_done[RG_AUDIT_RING] = {};    // recorded on the side stream after the entry's exact re-solves
   bool audit_inflight[RG_AUDIT_RING] = {};
   long long steps = 0;              // rg_mpc_step calls (ring entry and hash seed of the audit picks)
+  bool direct_on = false;           // persistently hard robots go straight to the exact lists (horizon 10, constant contacts, RG_SOLVER_AUTO)
+  hipStream_t direct_stream = nullptr;
+  hipEvent_t front_done = nullptr, direct_done = nullptr;
+  int *hint_host = nullptr;         // pinned: exact solves of a recent tick, written by the end-of-tick launch
+  long long direct_launches = 0;    // ticks whose direct lists had their own concurrent launch
 };
 
 // Every entry point runs on the handle's device and leaves the calling thread's current device as it found it: a process that
@@ -125,8 +130,10 @@ static thread_local std::string g_create_err;
 // i.e. without these streams and events, 0 of 60 processes).  A stream with cross-stream event waits behind it seems to be
 // what the runtime mishandles; recycling the objects sidesteps it and saves their creation cost per handle.
 struct AuditLane {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;                                      // audit lane: exact re-solves of converged robots
   hipEvent_t fused[RG_AUDIT_RING] = {}, done[RG_AUDIT_RING] = {};
+  hipStream_t direct = nullptr;                                      // direct lists: exact solves of persistently hard robots next to the ADMM launch
+  hipEvent_t front_done = nullptr, direct_done = nullptr;
 };
 static std::mutex g_lane_mu;
 static std::vector<AuditLane> g_lane_pool[64];   // per device
@@ -145,11 +152,17 @@ static hipError_t audit_lane_acquire(int device, AuditLane *lane) {
     e = hipEventCreateWithFlags(&lane->fused[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&lane->done[k], hipEventDisableTiming);
   }
+  // highest priority: its few workgroups (a whole CU each) must be placed BEFORE the ADMM launch's 4096, which becomes ready at
+  // the same moment -- at the default priority they only found a CU in that launch's tail and the tick waited for them after all
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&lane->direct, hipStreamNonBlocking, prio_high);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&lane->front_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&lane->direct_done, hipEventDisableTiming);
   return e;
 }
 static void audit_lane_release(int device, const AuditLane &lane) {
   if (!lane.stream) return;
   (void)hipStreamSynchronize(lane.stream);
+  (void)hipStreamSynchronize(lane.direct);
   std::lock_guard<std::mutex> lk(g_lane_mu);
   if (device >= 0 && device < 64) g_lane_pool[device].push_back(lane);
 }
@@ -300,14 +313,27 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.warm_key, B); AL(h->st.bins, RG_NLISTS * B); AL(h->counts2, 2 * RG_NCOUNTS); AL(h->st.iters, B); AL(h->st.ncs, B);
   h->st.counts = h->counts2; h->st.counts_next = h->counts2 + RG_NCOUNTS;
   AL(h->idx_dev, B); AL(h->t0_dev, B);
+  AL(h->st.hard, B);
+  h->direct_on = h->fused && h->auto_retry && cfg->horizon == 10 && !cfg->contact_lookahead;
+  if (h->direct_on) {
+    CR(hipHostMalloc((void **)&h->hint_host, 64, hipHostMallocDefault));
+    *h->hint_host = 0;
+    void *dp = nullptr;
+    CR(hipHostGetDevicePointer(&dp, h->hint_host, 0));
+    h->st.hint_host = (int *)dp;
+    AL(h->st.hint_dev, 1);
+  }
   h->audit_on = h->fused && cfg->audit_k > 0;
-  if (h->audit_on) {
-    AL(h->st.audit_rec, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * RG_REC_N); AL(h->st.audit_f, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * 12);
-    AL(h->st.audit_idx, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS); AL(h->st.audit_cnt, RG_AUDIT_RING); AL(h->st.audit_stat, 8);
+  if (h->audit_on || h->direct_on) {
     AuditLane lane;
     CR(audit_lane_acquire(device, &lane));
     h->audit_stream = lane.stream;
     for (int k = 0; k < RG_AUDIT_RING; k++) { h->audit_fused[k] = lane.fused[k]; h->audit_done[k] = lane.done[k]; }
+    h->direct_stream = lane.direct; h->front_done = lane.front_done; h->direct_done = lane.direct_done;
+  }
+  if (h->audit_on) {
+    AL(h->st.audit_rec, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * RG_REC_N); AL(h->st.audit_f, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS * 12);
+    AL(h->st.audit_idx, (size_t)RG_AUDIT_RING * RG_AUDIT_SLOTS); AL(h->st.audit_cnt, RG_AUDIT_RING); AL(h->st.audit_stat, 8);
   }
 #undef CR
 #undef AL
@@ -329,9 +355,11 @@ void rg_mpc_destroy(rg_mpc_handle *h) {
       AuditLane lane;
       lane.stream = h->audit_stream;
       for (int k = 0; k < RG_AUDIT_RING; k++) { lane.fused[k] = h->audit_fused[k]; lane.done[k] = h->audit_done[k]; }
+      lane.direct = h->direct_stream; lane.front_done = h->front_done; lane.direct_done = h->direct_done;
       audit_lane_release(h->device, lane);
     }
     for (void *p : h->allocs) (void)hipFree(p);
+    if (h->hint_host) (void)hipHostFree(h->hint_host);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   }
   delete h;
@@ -426,12 +454,25 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     h->st.audit_k = h->cfg.audit_k * RG_AUDIT_PERIOD; h->st.audit_ring = ring;
     h->st.audit_seed = (unsigned)((unsigned long long)h->steps * 0x632BE5ABull + 0x9E3779B9ull);
   }
+  // direct routing of persistently hard robots: the front kernel needs the tick; the exact solves of the direct lists get a
+  // launch of their own next to the ADMM launch when a recent tick had exact solves (pinned word, read without waiting: the
+  // host runs ticks ahead of the GPU, so this is a hint, and both paths are correct whatever it says)
+  h->st.direct_on = h->direct_on ? 1 : 0;
+  h->st.tick = (int)(h->steps & 0x7fffffff);
+  const bool direct_now = h->direct_on && *(volatile int *)h->hint_host > 0;
   h->steps++;
   hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
   hipLaunchKernelGGL(rg_front_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, di, dout, t, B);   // one wave per workgroup: 16 k lanes spread over all CUs
   HIPCHK(h, hipGetLastError());
   if (pev) HIPCHK(h, hipEventRecord(pev[1], s));
+  if (direct_now) {
+    HIPCHK(h, hipEventRecord(h->front_done, s));
+    HIPCHK(h, hipStreamWaitEvent(h->direct_stream, h->front_done, 0));
+    HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->direct_stream, RETRY_DIRECT));
+    HIPCHK(h, hipEventRecord(h->direct_done, h->direct_stream));
+    h->direct_launches++;
+  }
   if (h->fused) {
     // ADMM plans: one launch over all stance-leg counts, then the (normally empty) exact re-solve lists
     // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
@@ -440,7 +481,8 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
     else HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
     if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
     if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));
-    if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
+    if (direct_now) HIPCHK(h, hipStreamWaitEvent(s, h->direct_done, 0));   // the direct robots' actions are part of this tick
+    if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s, direct_now ? RETRY_LISTS : RETRY_ALL));
     else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
     if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
     if (ring >= 0) {
@@ -449,7 +491,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
       if (H == 10) {
         // three / four legs (and every robot of a contact schedule, entries of "four legs") on the 256-lane bodies, one / two
         // legs on the one-wave exact bodies: an exact solve then keeps one SIMD busy, not a whole CU
-        HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 2));
+        HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, RETRY_AUDIT34));
         HIPCHK(h, (launch_qp_tile_exact<2, 10, 8, 3>(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, false, h->st.audit_k + h->st.audit_k / 4)));
         HIPCHK(h, (launch_qp_tile_exact<1, 10, 4, 3>(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, false, 4)));
       } else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
@@ -583,6 +625,7 @@ int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iter
   // robots the ADMM pass left unconverged: re-solved exactly where the plan has a re-solve pass, failures otherwise
   int resolved = 0, unresolved = 0;
   for (int nc = 1; nc <= 4; nc++) (nc <= h->retry_max_nc ? resolved : unresolved) += cnt[8 + nc];
+  if (h->direct_on) resolved += cnt[1] + cnt[2] + cnt[3] + cnt[4];   // robots the front kernel sent straight to the exact solver
   if (retried) *retried = resolved;
   if (failures) *failures = cnt[7] + unresolved;
   return RG_MPC_OK;
@@ -608,6 +651,17 @@ int rg_mpc_audit_stats(rg_mpc_handle *h, int64_t *audited, int64_t *over_tol, do
   if (max_rel_elem) *max_rel_elem = me;
   if (exact_failures) *exact_failures = (int64_t)st8[4];
   if (dropped) *dropped = (int64_t)st8[5];
+  return RG_MPC_OK;
+}
+
+int rg_mpc_last_direct_count(rg_mpc_handle *h, int32_t *direct_robots, int64_t *concurrent_launches, void *stream) {
+  if (!h) return RG_MPC_ERR_INVALID;
+  DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
+  HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+  int cnt[RG_NCOUNTS];
+  HIPCHK(h, hipMemcpy(cnt, h->st.counts, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (direct_robots) *direct_robots = h->direct_on ? cnt[1] + cnt[2] + cnt[3] + cnt[4] : 0;
+  if (concurrent_launches) *concurrent_launches = h->direct_launches;
   return RG_MPC_OK;
 }
 

@@ -96,6 +96,14 @@ struct DevState {
   int *audit_idx;       // [RG_AUDIT_RING][RG_AUDIT_SLOTS] robot | re-solve list (stance legs) << 24
   int *audit_cnt;       // [RG_AUDIT_RING] picks of the tick that owns the ring entry (may exceed RG_AUDIT_SLOTS: the rest is dropped)
   unsigned long long *audit_stat;   // [8] audited, over_tol, max_rel bits, max_rel_elem bits, exact failures, dropped
+  // direct routing of persistently hard robots (horizon 10, constant contacts, RG_SOLVER_AUTO): a robot whose QP the exact
+  // solver had to take over is, while its contact set stays the same, sent straight to the exact lists by the front kernel
+  // (work lists 1..4, unused by the fused plan otherwise) instead of running ADMM to the cap again
+  int *hard;            // [B] contact mask + 1 of the tick in which the exact solver last solved the robot (0: none)
+  int *hint_host;       // pinned HOST word: exact solves (direct + re-solved) of a recent tick, read by rg_mpc_step without waiting
+  int *hint_dev;        // device copy of the value last written there
+  int direct_on;        // feature switch for this launch
+  int tick;             // rg_mpc_step count (every 16th tick a hard robot tries ADMM again)
   int audit_k;          // expected picks per tick for THIS launch (0: no capture)
   int audit_ring;       // ring entry of this tick
   unsigned audit_seed;  // per-tick hash seed

@@ -553,3 +553,44 @@ def test_strict_per_joint_reading_is_met_at_admm_tol_1e_7(oracle_lib):
     assert worst <= TORQUE_REL_TOL, worst
     helpers.assert_audit_clean(gpu[-1]["audit"])
     assert gpu[-1]["audit"]["audit_max_rel_elem"] <= TORQUE_REL_TOL
+
+
+def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
+    """Direct routing: a robot whose QP the exact solver had to take over is, while its contact set stays the same, sent
+    straight to the exact lists by the front kernel of the following ticks (every 16th tick it tries ADMM again) -- it would run
+    ADMM to the iteration cap again, and ONE such robot makes the whole launch wait for it.  A pace gait (statically unbalanced
+    leg pairs: fixed-rho ADMM does not converge) makes most two-leg robots hard.  Parity holds on every tick, the direct lists
+    fill after the first tick, those robots take no ADMM iterations, and once the pinned hint has reached the host the direct
+    lists run in their own launch next to the ADMM launch."""
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    import torch
+    cfg = MPCConfig.for_robot("ghost", duty_factor=(0.55,) * 4, init_phase=(0.0, 0.5, 0.0, 0.5), init_state=(1, 1, 1, 1))
+    B, ticks = 96, 20
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=3)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=ticks, jitter=0.1)
+    ctl = BatchedMPCController(B, cfg)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    direct, retried, capped, launches = [], [], [], 0
+    for k in range(ticks):
+        st = helpers.perturb(state, k, 0.1)
+        dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+        dev["contact"] = torch.from_numpy(synthetic.gait_consistent_contacts(cfg, 0.01 * k + t_off, state["_flip"])).cuda()
+        act = ctl.get_action(0.01 * k, dev)
+        torch.cuda.synchronize()
+        g = {"action": act.cpu().numpy().copy(), **{n: v.cpu().numpy().copy() for n, v in ctl.extra.items()}}
+        m = helpers.compare_tick(g, orc[k])
+        assert m["tau_rel_max"] <= TORQUE_REL_TOL and m["leg_state_mismatch"] == 0 and m["q_abs"] <= SWING_Q_ABS_TOL, (k, m)
+        stats = ctl.solver_stats()
+        assert stats["failures"] == 0, stats
+        n, launches = ctl._handle.last_direct_count(ctl._stream())
+        it, nc = ctl._handle.last_iterations(B, ctl._stream())
+        direct.append(n)
+        retried.append(stats["retried_exact"])
+        capped.append(int((it >= cfg.admm_iters).sum()))
+    print("exact solves per tick", retried, "of which sent straight to the exact solver", direct, "robots at the ADMM cap", capped, "concurrent launches", launches)
+    assert direct[0] == 0 and retried[0] >= 1, (direct, retried)          # first tick: ADMM runs to the cap, then the exact pass
+    assert sum(direct[1:]) >= 0.5 * sum(retried[1:]) > 0, (direct, retried)   # from then on most exact solves are of robots that skipped ADMM ...
+    assert sum(capped[1:]) <= 0.5 * sum(retried[1:]), (capped, retried)   # ... only robots whose contact set just changed, or on their 16th-tick ADMM probe, run to the cap
+    assert launches >= sum(1 for r in retried[:-1] if r > 0) - 2, (launches, retried)   # a tick after exact solves gives the direct lists their own launch
+    ctl.close()
