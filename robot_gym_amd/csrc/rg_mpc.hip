@@ -11,7 +11,9 @@
 //                              for 3-4 legs and for contact schedules), J' f, 60-float action row.
 //   rg_qp_fused_retry_kernel / rg_qp_admm_tile_kernel<..., true>
 //                              exact dual active-set re-solve of the robots ADMM left unconverged (RG_SOLVER_AUTO),
-//                              or of every robot (RG_SOLVER_ACTIVE_SET).
+//                              or of every robot (RG_SOLVER_ACTIVE_SET).  The same exact bodies also serve two side
+//                              streams: the audit lane (converged robots re-solved and compared, rg_qp_common.inc) and
+//                              the direct lists (persistently hard robots solved next to the ADMM launch).
 // Every accepted configuration has a GPU-tested instantiation; anything else is rejected by rg_mpc_create.
 // No MFMA: the per-robot blocks are 6..12 wide and every robot has its own operands.
 #include "rg_mpc_dev.h"
