@@ -594,3 +594,26 @@ def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
     assert sum(capped[1:]) <= 0.5 * sum(retried[1:]), (capped, retried)   # ... only robots whose contact set just changed, or on their 16th-tick ADMM probe, run to the cap
     assert launches >= sum(1 for r in retried[:-1] if r > 0) - 2, (launches, retried)   # a tick after exact solves gives the direct lists their own launch
     ctl.close()
+
+
+@pytest.mark.parametrize("horizon", [10, 20])
+def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon):
+    """Guard for the exact re-solve launch (rg_qp_fused_retry_kernel / rg_qp_sched_retry_kernel: all exact bodies of a horizon
+    inlined behind one work loop, the kernel whose code generation DESIGN.md section 9 records as fragile): ADMM is cut off after
+    8 iterations, so EVERY robot with a stance leg is handed to it; per-robot duty factors from 0.3 to 0.9 put one-, two-,
+    three- and four-leg robots into the same launch, and 1024 robots on 128 workgroups make every workgroup run several bodies
+    one after the other.  Exact solves: agreement with the oracle to float32 output rounding, no breakdowns."""
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon, admm_iters=8)
+    B = 1024
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=71)
+    gait = synthetic.random_gaits(B, cfg, seed=71, duty_range=(0.3, 0.9))
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait)
+    _check(gpu, orc)
+    for k, g in enumerate(gpu):
+        bins, stats = g["bins"], g["solver_stats"]
+        assert min(bins[1:]) > 0, bins                       # all four stance-leg counts in the launch
+        assert stats["failures"] == 0, (k, stats)
+        assert stats["retried_exact"] >= 0.9 * sum(bins[1:]), (k, stats, bins)   # (a robot can converge within 8 iterations; hardly any does)
+        m = helpers.compare_tick(g, orc[k])
+        assert m["grf_rel_max"] <= 2e-5, (k, m)
