@@ -600,13 +600,17 @@ def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
 def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon):
     """Guard for the exact re-solve launch (rg_qp_fused_retry_kernel / rg_qp_sched_retry_kernel: all exact bodies of a horizon
     inlined behind one work loop, the kernel whose code generation DESIGN.md section 9 records as fragile): ADMM is cut off after
-    8 iterations, so EVERY robot with a stance leg is handed to it; per-robot duty factors from 0.3 to 0.9 put one-, two-,
-    three- and four-leg robots into the same launch, and 1024 robots on 128 workgroups make every workgroup run several bodies
+    8 iterations, so EVERY robot with a stance leg is handed to it; per-robot duty factors from 0.3 to 0.9, half of the robots
+    trotting and half walking, put one-, two-, three- and four-leg robots into the same launch, and 1024 robots on 128 workgroups make every workgroup run several bodies
     one after the other.  Exact solves: agreement with the oracle to float32 output rounding, no breakdowns."""
     cfg = MPCConfig.for_robot("ghost", horizon=horizon, admm_iters=8)
     B = 1024
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=71)
     gait = synthetic.random_gaits(B, cfg, seed=71, duty_range=(0.3, 0.9))
+    gait["init_state"] = np.ascontiguousarray(gait["init_state"])
+    gait["init_state"][:, ::2] = 1            # every other robot walks (quarter-cycle phase offsets): one leg down at duty 0.3, three at 0.8
+    gait["init_phase"] = gait["init_phase"].copy()
+    gait["init_phase"][:, ::2] = np.array([0.0, 0.5, 0.25, 0.75])[:, None]
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait)
     _check(gpu, orc)
