@@ -119,7 +119,7 @@ typedef struct {
                                steady ratio r -> jump by r / (1 - r) of the last displacement).  Cuts the few crawling robots
                                per tick that bound the launch by a third to a half; a robot that has jumped has to pass
                                stricter stopping tests.  Not applied to single-leg stance.  0 = off */
-  double admm_extrap;       /* 5: third convergence condition -- the distance still to go estimated from the shrink rate of
+  double admm_extrap;       /* 1.5: third convergence condition -- the distance still to go estimated from the shrink rate of
                                the movement per vote window, m r / (1 - r), must be below admm_extrap * admm_tol * m * g
                                (stops crawling robots from passing the "stopped moving" test early); 0 = off */
   /* thresholds of the dominant-mode extrapolation (tuned constants, like every other one an explicit field):

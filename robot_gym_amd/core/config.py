@@ -68,7 +68,7 @@ class MPCConfig:
     admm_rho2: float = 5e-4      # second ADMM stage: robots not converged after admm_switch
     admm_switch: int = 150       # iterations are re-factorised with admm_rho2 and continue from their iterate (0 rho2 = off)
     admm_accel: int = 80         # votes from this iteration on may extrapolate (z, y) along the dominant mode (cuts the crawling robots by a third to a half; 0 = off).  80: only robots well past the population's natural tail (p99.9 ~ 90-115) jump -- measured 20..100: 40 costs the headline 1 %, config 2 4 % and config 5 8 % against 80
-    admm_extrap: float = 5.0     # convergence also needs the geometric estimate of the remaining distance below admm_extrap * tol (0 = off)
+    admm_extrap: float = 1.5     # convergence also needs the geometric estimate of the remaining distance below admm_extrap * tol (0 = off); 1.5: that distance (N) times a 0.35 m lever arm is the 1e-4 N m of the parity bar
     # thresholds of the dominant-mode extrapolation: jump when cos^2 of consecutive window displacements
     # > accel_cos2 and their shrink ratio r is in (accel_rmin, accel_rmax); rate guard of jumped robots capped at accel_rate_cap
     accel_cos2: float = 0.9

@@ -596,8 +596,9 @@ def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
     ctl.close()
 
 
+@pytest.mark.parametrize("seed", [71 + 7 * i for i in range(int(os.environ.get("RG_GUARD_SEEDS", "1")))])
 @pytest.mark.parametrize("horizon", [10, 20])
-def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon):
+def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon, seed):
     """Guard for the exact re-solve launch (rg_qp_fused_retry_kernel / rg_qp_sched_retry_kernel: all exact bodies of a horizon
     inlined behind one work loop, the kernel whose code generation DESIGN.md section 9 records as fragile): ADMM is cut off after
     8 iterations, so EVERY robot with a stance leg is handed to it; per-robot duty factors from 0.3 to 0.9, half of the robots
@@ -605,8 +606,8 @@ def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon):
     one after the other.  Exact solves: agreement with the oracle to float32 output rounding, no breakdowns."""
     cfg = MPCConfig.for_robot("ghost", horizon=horizon, admm_iters=8)
     B = 1024
-    state, cmd, t_off = synthetic.make_states(B, cfg, seed=71)
-    gait = synthetic.random_gaits(B, cfg, seed=71, duty_range=(0.3, 0.9))
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed)
+    gait = synthetic.random_gaits(B, cfg, seed=seed, duty_range=(0.3, 0.9))
     gait["init_state"] = np.ascontiguousarray(gait["init_state"])
     gait["init_state"][:, ::2] = 1            # every other robot walks (quarter-cycle phase offsets): one leg down at duty 0.3, three at 0.8
     gait["init_phase"] = gait["init_phase"].copy()
