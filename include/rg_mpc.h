@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RG_MPC_ABI_VERSION 3
+#define RG_MPC_ABI_VERSION 4
 #define RG_MPC_MAX_HORIZON 20
 #define RG_MPC_NUM_LEGS 4
 #define RG_MPC_NUM_MOTORS 12
@@ -48,10 +48,17 @@ typedef enum {
 enum { RG_LEG_SWING = 0, RG_LEG_STANCE = 1, RG_LEG_EARLY_CONTACT = 2, RG_LEG_LOSE_CONTACT = 3 };
 
 /* RG_SOLVER_ADMM: friction-cone ADMM only (iteration cap admm_iters); unconverged robots are counted as failures.
- * RG_SOLVER_ACTIVE_SET: exact dual active-set method only (horizon 10).
+ * RG_SOLVER_ACTIVE_SET: exact dual active-set method only (horizon 10): one / two stance legs in the QP launch, three /
+ *   four legs (and every robot of a contact schedule) in the exact re-solve launch.
  * RG_SOLVER_AUTO: ADMM first; robots that have not converged after admm_iters iterations are
- *   re-solved exactly by the active-set kernel (second launch over a retry list). */
-enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1, RG_SOLVER_AUTO = 2 };
+ *   re-solved exactly by the active-set kernel (second launch over a retry list).
+ * RG_SOLVER_HYBRID (default): what the reference's default solver computes -- the exact minimiser (upstream qpOASES, an
+ *   online active-set method; mpc_controller.py:47-56 passes no solver) -- for the robots where it is also the cheaper way:
+ *   one and two stance legs (every robot of a trot, 60 variables, one or two active constraints at the optimum) are solved
+ *   by a one-wave dual active-set body warm-started from the robot's working set of the previous tick (warm_start); three
+ *   and four legs keep the wrench-space ADMM with the exact re-solve behind it, as under RG_SOLVER_AUTO.  At horizon 20 and
+ *   with contact_lookahead it is RG_SOLVER_AUTO. */
+enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1, RG_SOLVER_AUTO = 2, RG_SOLVER_HYBRID = 3 };
 
 /* Everything MPCController._setup_controller wires (mpc_controller.py:28-66) plus the
  * upstream module defaults it does not override, as explicit fields. */
@@ -91,7 +98,7 @@ typedef struct {
   double toe_com[12];
   double base_com[3];
   int32_t ik_iters;         /* fixed damped-Newton iteration count (8; converged to 1e-14 after 6 on swing-size moves) */
-  int32_t solver;           /* RG_SOLVER_* (default RG_SOLVER_AUTO) */
+  int32_t solver;           /* RG_SOLVER_* (default RG_SOLVER_HYBRID) */
   double ik_damping;        /* lambda^2 */
   double ik_max_step;       /* rad per iteration */
   /* friction-cone ADMM */
@@ -107,7 +114,8 @@ typedef struct {
                                rg_mpc_state_ptrs.contact_sched when given, else the open-loop desired contact state at
                                t + k*dt_plan */
   int32_t warm_start;       /* 1: start ADMM from the robot's previous-tick (z, y) (stored as float32) while its contact set is
-                               unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve.
+                               unchanged, as upstream's OSQP path does; results stay within admm_tol of the cold solve; the
+                               exact body starts from the robot's previous working set (the result is the same minimiser).
                                0: cold start every tick.  (Not used by the contact-schedule body.) */
   int32_t reserved2;        /* must be 0 */
   /* second ADMM stage: robots not converged after admm_switch iterations are re-factorised with
@@ -137,6 +145,10 @@ typedef struct {
   int32_t audit_k;          /* 8 */
   int32_t reserved3;        /* must be 0 */
   double audit_tol;         /* 1e-4: per-robot torque error max_j |dtau_j| / max(max_j |tau_j|, 1 N m) counted as over tolerance */
+  double admm_rho34_scale;  /* first-stage rho of the wrench-space ADMM body (three and four stance legs, horizon 10) = admm_rho x this.
+                               Its iteration count falls with rho at every percentile (admm_rho x 0.5: mean 54 -> ~43), where the
+                               force-space body's tail grows; with the exact body taking the one- and two-leg robots
+                               (RG_SOLVER_HYBRID) these robots are the launch's longest jobs */
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per

@@ -20,6 +20,30 @@
 #endif
 
 /* ------------------------------------------------------------------------------------ */
+/* per-thread workspace                                                                  */
+/* ------------------------------------------------------------------------------------ */
+/* Every dense temporary of a tick (the 13H x 12H condensed matrices, the Hessian, the active-set solver's factors: ~20
+ * buffers, up to ~5 MB at horizon 20) comes from a per-thread bump arena instead of malloc / calloc / free: with one
+ * heap call per buffer inside the OpenMP loop over robots the port stopped scaling at ~32 threads (the allocator's
+ * locks and page faults, not the arithmetic: round-3 review).  The public entry points take a mark on entry and release
+ * back to it on exit (stack discipline, so nested entry points work); the arena itself is allocated once per thread and
+ * kept (untouched pages of it are never committed). */
+#define WS_BYTES ((size_t)64 << 20)
+static __thread unsigned char *ws_base;
+static __thread size_t ws_top;
+static void *ws_alloc(size_t bytes) {
+  if (!ws_base) { ws_base = malloc(WS_BYTES); if (!ws_base) { fprintf(stderr, "mpc_oracle: workspace allocation failed\n"); abort(); } }
+  bytes = (bytes + 63) & ~(size_t)63;
+  if (ws_top + bytes > WS_BYTES) { fprintf(stderr, "mpc_oracle: per-thread workspace exhausted\n"); abort(); }
+  void *p = ws_base + ws_top;
+  ws_top += bytes;
+  return p;
+}
+static void *ws_calloc(size_t n, size_t size) { void *p = ws_alloc(n * size); memset(p, 0, n * size); return p; }
+static size_t ws_mark(void) { return ws_top; }
+static void ws_release(size_t mark) { ws_top = mark; }
+
+/* ------------------------------------------------------------------------------------ */
 /* defaults: ghost                                                                       */
 /* ------------------------------------------------------------------------------------ */
 void orc_default_config(orc_config *c) {
@@ -262,7 +286,7 @@ static void expm_dense(int n, const double *M, double *E) {
   for (int i = 0; i < n; i++) { double s = 0; for (int j = 0; j < n; j++) s += fabs(M[i * n + j]); if (s > nrm) nrm = s; }
   int sq = 0; double sc = 1.0;
   while (nrm * sc > 0.25) { sc *= 0.5; sq++; }
-  double *A = malloc(sizeof(double) * n * n), *T = malloc(sizeof(double) * n * n), *T2 = malloc(sizeof(double) * n * n);
+  double *A = ws_alloc(sizeof(double) * n * n), *T = ws_alloc(sizeof(double) * n * n), *T2 = ws_alloc(sizeof(double) * n * n);
   for (int i = 0; i < n * n; i++) A[i] = M[i] * sc;
   for (int i = 0; i < n * n; i++) { E[i] = 0; T[i] = 0; }
   for (int i = 0; i < n; i++) { E[i * n + i] = 1; T[i * n + i] = 1; }
@@ -271,7 +295,6 @@ static void expm_dense(int n, const double *M, double *E) {
     for (int i = 0; i < n * n; i++) { T[i] = T2[i] / k; E[i] += T[i]; }
   }
   for (int s = 0; s < sq; s++) { matmul(n, n, n, E, E, T2); memcpy(E, T2, sizeof(double) * n * n); }
-  free(A); free(T); free(T2);
 }
 
 /* dense, all four legs: P (12H x 12H) and q (12H); caller frees */
@@ -292,7 +315,7 @@ static void mpc_build_dense(const orc_config *c, const double rpy_in[3], const d
   for (int i = 0; i < 4; i++) if (contact[i]) { hz += fw[i][2]; ncontact++; }
   double com_z = ncontact > 0 ? fabs(hz / ncontact) : 0.0;
   double x0[13] = {rpy[0], rpy[1], rpy[2], 0, 0, com_z, omega[0], omega[1], omega[2], v_body[0], v_body[1], v_body[2], -c->gravity};
-  double *xd = calloc((size_t)NX * H, sizeof(double));
+  double *xd = ws_calloc((size_t)NX * H, sizeof(double));
   for (int i = 0; i < H; i++) {
     double *d = xd + i * NX;
     d[0] = 0; d[1] = 0; d[2] = rpy[2] + c->dt_plan * (i + 1) * cmd[2];
@@ -345,8 +368,8 @@ static void mpc_build_dense(const orc_config *c, const double rpy_in[3], const d
   if (Ad_out) memcpy(Ad_out, Ad, sizeof(Ad));
   if (Bd_out) memcpy(Bd_out, Bd, sizeof(Bd));
   /* CalculateQpMats: a_qp blocks = Ad^(k+1); anb[i] = Ad^i Bd; dense b_qp */
-  double *aqp = calloc((size_t)NX * H * NX, sizeof(double));
-  double *anb = calloc((size_t)NX * H * NU, sizeof(double));
+  double *aqp = ws_calloc((size_t)NX * H * NX, sizeof(double));
+  double *anb = ws_calloc((size_t)NX * H * NU, sizeof(double));
   memcpy(aqp, Ad, sizeof(Ad));
   memcpy(anb, Bd, sizeof(Bd));
   for (int i = 1; i < H; i++) {
@@ -354,32 +377,31 @@ static void mpc_build_dense(const orc_config *c, const double rpy_in[3], const d
     matmul(NX, NX, NU, Ad, anb + (size_t)(i - 1) * NX * NU, anb + (size_t)i * NX * NU);
   }
   const int NR = NX * H, NC = NU * H;
-  double *bqp = calloc((size_t)NR * NC, sizeof(double));
+  double *bqp = ws_calloc((size_t)NR * NC, sizeof(double));
   for (int i = 0; i < H; i++) for (int j = 0; j <= i; j++) {
     const double *blk = anb + (size_t)(i - j) * NX * NU;
     for (int r = 0; r < NX; r++) for (int cc = 0; cc < NU; cc++) bqp[(size_t)(i * NX + r) * NC + j * NU + cc] = blk[r * NU + cc];
   }
   /* P = 2 B'WB + alpha I ; q = 2 B'W (A_qp x0 - X*) */
-  double *WB = malloc(sizeof(double) * NR * NC);
+  double *WB = ws_alloc(sizeof(double) * NR * NC);
   for (int r = 0; r < NR; r++) { double w = c->weights[r % NX]; for (int cc = 0; cc < NC; cc++) WB[(size_t)r * NC + cc] = w * bqp[(size_t)r * NC + cc]; }
-  double *P = calloc((size_t)NC * NC, sizeof(double));
+  double *P = ws_calloc((size_t)NC * NC, sizeof(double));
   for (int i = 0; i < NC; i++) for (int j = i; j < NC; j++) {
     double s = 0; for (int r = 0; r < NR; r++) s += bqp[(size_t)r * NC + i] * WB[(size_t)r * NC + j];
     P[(size_t)i * NC + j] = 2 * s; P[(size_t)j * NC + i] = 2 * s;
   }
   for (int i = 0; i < NC; i++) P[(size_t)i * NC + i] += c->alpha;
-  double *sd = malloc(sizeof(double) * NR);
+  double *sd = ws_alloc(sizeof(double) * NR);
   for (int i = 0; i < H; i++) for (int r = 0; r < NX; r++) {
     double s = 0; for (int k = 0; k < NX; k++) s += aqp[(size_t)i * NX * NX + r * NX + k] * x0[k];
     sd[i * NX + r] = s - xd[i * NX + r];
   }
-  double *qf = malloc(sizeof(double) * NC);
+  double *qf = ws_alloc(sizeof(double) * NC);
   for (int i = 0; i < NC; i++) { double s = 0; for (int r = 0; r < NR; r++) s += WB[(size_t)r * NC + i] * sd[r]; qf[i] = 2 * s; }
-  free(xd); free(aqp); free(anb); free(bqp); free(WB); free(sd);
   *P_out = P; *q_out = qf;
 }
 
-int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+static int orc_mpc_build_impl(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
                   const double foot_pos[12], const int contact[4], const double cmd[3],
                   double *Pr, double *qr, int legs[4], double *Ad_out, double *Bd_out) {
   const int H = c->horizon, NU = 12, NC = NU * H;
@@ -396,13 +418,20 @@ int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omeg
       Pr[(size_t)ir * n + jr] = P[(size_t)i_f * NC + jf];
     }
   }
-  free(P); free(qf);
   return nc;
+}
+int orc_mpc_build(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+                  const double foot_pos[12], const int contact[4], const double cmd[3],
+                  double *Pr, double *qr, int legs[4], double *Ad_out, double *Bd_out) {
+  const size_t mark = ws_mark();   /* per-thread workspace: everything this call allocates is released on return */
+  const int r = orc_mpc_build_impl(c, rpy_in, omega, v_body, foot_pos, contact, cmd, Pr, qr, legs, Ad_out, Bd_out);
+  ws_release(mark);
+  return r;
 }
 
 /* EXTENSION: per-step contact schedule.  Same dense P, q; a (step, leg) block
  * exists only where sched says the leg is in contact at that step. */
-int orc_mpc_build_sched(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+static int orc_mpc_build_sched_impl(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
                         const double foot_pos[12], const int contact[4], const int *sched, const double cmd[3],
                         double *Pr, double *qr, int *var_step, int *var_leg) {
   const int H = c->horizon, NU = 12, NC = NU * H;
@@ -419,8 +448,15 @@ int orc_mpc_build_sched(const orc_config *c, const double rpy_in[3], const doubl
       Pr[(size_t)ir * n + jr] = P[(size_t)i_f * NC + jf];
     }
   }
-  free(P); free(qf);
   return n;
+}
+int orc_mpc_build_sched(const orc_config *c, const double rpy_in[3], const double omega[3], const double v_body[3],
+                        const double foot_pos[12], const int contact[4], const int *sched, const double cmd[3],
+                        double *Pr, double *qr, int *var_step, int *var_leg) {
+  const size_t mark = ws_mark();   /* per-thread workspace: everything this call allocates is released on return */
+  const int r = orc_mpc_build_sched_impl(c, rpy_in, omega, v_body, foot_pos, contact, sched, cmd, Pr, qr, var_step, var_leg);
+  ws_release(mark);
+  return r;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -516,12 +552,12 @@ static void project_pyramid(double a, double b, double c, double mu, double lo, 
 
 static int qp_admm_fixed(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x) {
   const int nb = n / 3;
-  double *L = malloc(sizeof(double) * n * n), *z = calloc(n, sizeof(double)), *y = calloc(n, sizeof(double)), *u = malloc(sizeof(double) * n);
+  double *L = ws_alloc(sizeof(double) * n * n), *z = ws_calloc(n, sizeof(double)), *y = ws_calloc(n, sizeof(double)), *u = ws_alloc(sizeof(double) * n);
   for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) L[i * n + j] = P[i * n + j] + (i == j ? g_admm_rho : 0.0);
   for (int j = 0; j < n; j++) {
     double s = L[j * n + j];
     for (int k = 0; k < j; k++) s -= L[j * n + k] * L[j * n + k];
-    if (!(s > 0)) { free(L); free(z); free(y); free(u); return -1; }
+    if (!(s > 0)) { return -1; }
     double d = sqrt(s); L[j * n + j] = d;
     for (int i = j + 1; i < n; i++) { double t = L[i * n + j]; for (int k = 0; k < j; k++) t -= L[i * n + k] * L[j * n + k]; L[i * n + j] = t / d; }
   }
@@ -537,19 +573,18 @@ static int qp_admm_fixed(int n, const double *P, const double *qv, const double 
     }
   }
   memcpy(x, z, sizeof(double) * n);
-  free(L); free(z); free(y); free(u);
   return g_admm_iters;
 }
 
-int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]) {
+static int orc_qp_solve_impl(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]) {
   const int nb = n / 3, m = 6 * nb;
   if (n == 0) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; return 0; }
   if (g_qp_mode == 1) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; return qp_admm_fixed(n, P, qv, mu_blk, fz_lo, fz_hi, x); }
-  double *L = malloc(sizeof(double) * n * n), *J = calloc((size_t)n * n, sizeof(double)), *R = calloc((size_t)n * n, sizeof(double));
-  double *d = malloc(sizeof(double) * n), *z = malloc(sizeof(double) * n), *r = malloc(sizeof(double) * n);
-  double *u = calloc((size_t)m + 1, sizeof(double)), *s = malloc(sizeof(double) * m);
-  double *x_old = malloc(sizeof(double) * n), *u_old = malloc(sizeof(double) * (m + 1));
-  int *A = calloc((size_t)m + 1, sizeof(int)), *A_old = malloc(sizeof(int) * (m + 1)), *iai = malloc(sizeof(int) * m), *excl = malloc(sizeof(int) * m);
+  double *L = ws_alloc(sizeof(double) * n * n), *J = ws_calloc((size_t)n * n, sizeof(double)), *R = ws_calloc((size_t)n * n, sizeof(double));
+  double *d = ws_alloc(sizeof(double) * n), *z = ws_alloc(sizeof(double) * n), *r = ws_alloc(sizeof(double) * n);
+  double *u = ws_calloc((size_t)m + 1, sizeof(double)), *s = ws_alloc(sizeof(double) * m);
+  double *x_old = ws_alloc(sizeof(double) * n), *u_old = ws_alloc(sizeof(double) * (m + 1));
+  int *A = ws_calloc((size_t)m + 1, sizeof(int)), *A_old = ws_alloc(sizeof(int) * (m + 1)), *iai = ws_alloc(sizeof(int) * m), *excl = ws_alloc(sizeof(int) * m);
   int iter = 0, ret = -1;
   /* Cholesky P = L L' */
   memcpy(L, P, sizeof(double) * n * n);
@@ -633,17 +668,21 @@ int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk,
   if (kkt) {
     /* KKT residuals with the final multipliers */
     double st = 0, pf = 0, cs = 0;
-    double *g = malloc(sizeof(double) * n);
+    double *g = ws_alloc(sizeof(double) * n);
     for (int i = 0; i < n; i++) { double v = qv[i]; for (int j = 0; j < n; j++) v += P[(size_t)i * n + j] * x[j]; g[i] = v; }
     for (int k = 0; k < iq; k++) { crow rw = make_row(A[k], mu_blk, fz_lo, fz_hi); g[rw.i0] -= u[k] * rw.v0; g[rw.i1] -= u[k] * rw.v1; double sv = row_eval(&rw, x); if (fabs(u[k] * sv) > cs) cs = fabs(u[k] * sv); if (u[k] < -1e-9) cs = fmax(cs, -u[k]); }
     for (int i = 0; i < n; i++) if (fabs(g[i]) > st) st = fabs(g[i]);
     for (int i = 0; i < m; i++) { crow rw = make_row(i, mu_blk, fz_lo, fz_hi); double sv = row_eval(&rw, x); if (-sv > pf) pf = -sv; }
     kkt[0] = st; kkt[1] = pf; kkt[2] = cs;
-    free(g);
   }
 done:
-  free(L); free(J); free(R); free(d); free(z); free(r); free(u); free(s); free(x_old); free(u_old); free(A); free(A_old); free(iai); free(excl);
   return ret;
+}
+int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]) {
+  const size_t mark = ws_mark();   /* per-thread workspace: everything this call allocates is released on return */
+  const int r = orc_qp_solve_impl(n, P, qv, mu_blk, fz_lo, fz_hi, x, kkt);
+  ws_release(mark);
+  return r;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -672,7 +711,7 @@ static void quat_inv_rotate(const double q[4], const double v[3], double o[3]) {
   o[2] = v[2] + w * tz + (x * ty - y * tx);
 }
 
-int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *in, orc_output *out) {
+static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const orc_input *in, orc_output *out) {
   memset(out, 0, sizeof(*out));
   const int H = c->horizon;
   /* kinematics inputs */
@@ -725,7 +764,7 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
   double grf[12] = {0};
   if (c->contact_lookahead) {
     /* EXTENSION: step k uses the open-loop desired state at t + k dt_plan (k = 0 is the current tick) */
-    int *sched = malloc(sizeof(int) * 4 * H), nb = 0;
+    int *sched = ws_alloc(sizeof(int) * 4 * H), nb = 0;
     for (int k = 0; k < H; k++) {
       int des[4];
       if (in->sched_valid) { for (int l = 0; l < 4; l++) des[l] = ((in->sched[l] >> k) & 1) ? ORC_STANCE : ORC_SWING; }   /* caller's schedule */
@@ -736,22 +775,20 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
     nb = 0; for (int i = 0; i < 4 * H; i++) nb += sched[i];
     int n = 3 * nb;
     if (n > 0 && nc_guess > 0) {
-      double *P = malloc(sizeof(double) * n * n), *qv = malloc(sizeof(double) * n), *u = malloc(sizeof(double) * n), *mu_blk = malloc(sizeof(double) * nb);
-      int *vs = malloc(sizeof(int) * nb), *vl = malloc(sizeof(int) * nb);
+      double *P = ws_alloc(sizeof(double) * n * n), *qv = ws_alloc(sizeof(double) * n), *u = ws_alloc(sizeof(double) * n), *mu_blk = ws_alloc(sizeof(double) * nb);
+      int *vs = ws_alloc(sizeof(int) * nb), *vl = ws_alloc(sizeof(int) * nb);
       orc_mpc_build_sched(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, sched, in->cmd, P, qv, vs, vl);
       for (int b2 = 0; b2 < nb; b2++) mu_blk[b2] = c->mu[0];
       double mg = c->mass * c->gravity;
       out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
       int bad = out->qp_iters < 0;
       if (!bad) for (int b2 = 0; b2 < nb && vs[b2] == 0; b2++) for (int a = 0; a < 3; a++) grf[3 * vl[b2] + a] = -u[3 * b2 + a];
-      free(P); free(qv); free(u); free(mu_blk); free(vs); free(vl);
-      if (bad) { free(sched); return -1; }
+      if (bad) { return -1; }
     }
-    free(sched);
   } else {
   int n = 3 * nc_guess * H;
   if (n > 0) {
-    double *P = malloc(sizeof(double) * n * n), *qv = malloc(sizeof(double) * n), *u = malloc(sizeof(double) * n), *mu_blk = malloc(sizeof(double) * (n / 3));
+    double *P = ws_alloc(sizeof(double) * n * n), *qv = ws_alloc(sizeof(double) * n), *u = ws_alloc(sizeof(double) * n), *mu_blk = ws_alloc(sizeof(double) * (n / 3));
     int legs[4];
     int nc = orc_mpc_build(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, in->cmd, P, qv, legs, NULL, NULL);
     /* UpdateConstraintsMatrix uses friction_coeff[0..3] on the four cone ROWS of every block;
@@ -759,9 +796,8 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
     for (int b = 0; b < n / 3; b++) mu_blk[b] = c->mu[0];
     double mg = c->mass * c->gravity;
     out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
-    if (out->qp_iters < 0) { free(P); free(qv); free(u); free(mu_blk); return -1; }
+    if (out->qp_iters < 0) { return -1; }
     for (int l = 0; l < nc; l++) for (int a = 0; a < 3; a++) grf[3 * legs[l] + a] = -u[3 * l + a]; /* negated first step */
-    free(P); free(qv); free(u); free(mu_blk);
   }
   }
   memcpy(out->grf, grf, sizeof(grf));
@@ -780,6 +816,12 @@ int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *i
   for (int leg = 0; leg < 4; leg++) { out->desired[leg] = s->desired[leg]; out->leg_state[leg] = s->leg_state[leg]; out->phase[leg] = s->phase[leg]; }
   memcpy(out->v_body, s->v_body, sizeof(double) * 3);
   return 0;
+}
+int orc_step(const orc_config *c, orc_state *s, double t_now, const orc_input *in, orc_output *out) {
+  const size_t mark = ws_mark();   /* per-thread workspace: everything this call allocates is released on return */
+  const int r = orc_step_impl(c, s, t_now, in, out);
+  ws_release(mark);
+  return r;
 }
 
 int orc_step_batch_cfgs(const orc_config *cfgs, orc_state *s, int B, double t_now, const orc_input *in, orc_output *out, int nthreads) {

@@ -16,6 +16,7 @@ from robot_gym_amd.model.robots.robot_constants import ROBOTS, RobotConstants
 SOLVER_ADMM = 0
 SOLVER_ACTIVE_SET = 1
 SOLVER_AUTO = 2
+SOLVER_HYBRID = 3   # exact active set for one / two stance legs, wrench-space ADMM (exact re-solve behind it) for three / four
 
 
 @dataclass
@@ -53,14 +54,14 @@ class MPCConfig:
     toe_com: Tuple[float, ...] = (0.0,) * 12
     base_com: Tuple[float, ...] = (0.0,) * 3
     ik_iters: int = 8
-    solver: int = SOLVER_AUTO
+    solver: int = SOLVER_HYBRID
     ik_damping: float = 1e-10
     ik_max_step: float = 0.5
     admm_iters: int = 450        # ADMM cap over both stages (robots beyond it go to the exact solver under SOLVER_AUTO); exact count when admm_tol == 0
     reserved0: int = 0           # must be 0 (rg_mpc_create rejects anything else)
     admm_rho: float = 1e-4
     admm_relax: float = 1.8
-    admm_tol: float = 1e-6       # stop when no force moved more than admm_tol*m*g over admm_check iterations
+    admm_tol: float = 1e-7       # stop when no force moved more than admm_tol*m*g over admm_check iterations (1e-7: every JOINT torque within 1e-4 of max(|tau_j|, 1 N m), the strict reading of the parity bar; 1e-6 meets it per robot only, 5 % faster)
     admm_check: int = 5          # convergence check period (5: -11 % iterations vs 10 at 6x the residual error, still 60x inside the tolerance)
     contact_lookahead: int = 0   # extension: per-horizon-step contact schedule (caller-supplied, else from the open-loop gait)
     warm_start: int = 1          # ADMM starts from the robot's previous-tick (z, y) (kept as float32) while its contact set is unchanged, like upstream's OSQP path; 0 = cold start every tick
@@ -78,6 +79,7 @@ class MPCConfig:
     audit_k: int = 8             # audit lane: ~audit_k converged ADMM solves per tick are re-solved exactly on a side stream and compared (0 = off)
     reserved3: int = 0           # must be 0
     audit_tol: float = 1e-4      # per-robot torque error the audit counts as over tolerance
+    admm_rho34_scale: float = 0.5   # first-stage rho of the wrench-space ADMM body (three / four legs, horizon 10) = admm_rho x this: its iteration count falls with rho at every percentile (1.0: mean 54, 0.5: 43; measured 0.3 ... 1.0, profiles/r4_rho34.txt)
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

@@ -12,7 +12,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
 # RG_MPC_LIB: load another build of the same C-ABI (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("RG_MPC_LIB") or os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 AUDIT_PERIOD = 8   # RG_MPC_AUDIT_PERIOD: the audit lane picks on the first tick and then on every 8th one (ticks 4, 12, 20 ...)
 d = C.c_double
 i32 = C.c_int32
@@ -38,7 +38,7 @@ class CConfig(C.Structure):
         ("admm_tol", d), ("admm_check", i32), ("contact_lookahead", i32), ("warm_start", i32), ("reserved2", i32),
         ("admm_rho2", d), ("admm_switch", i32), ("admm_accel", i32), ("admm_extrap", d),
         ("accel_cos2", d), ("accel_rmax", d), ("accel_rmin", d), ("accel_rate_cap", d),
-        ("audit_k", i32), ("reserved3", i32), ("audit_tol", d),
+        ("audit_k", i32), ("reserved3", i32), ("audit_tol", d), ("admm_rho34_scale", d),
     ]
 
 

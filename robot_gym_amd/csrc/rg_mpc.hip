@@ -9,11 +9,15 @@
 //                              count in one launch: closed-form Kronecker QP assembly, in-register symmetric sweep
 //                              inverse, over-relaxed friction-pyramid ADMM (force space for 1-2 legs, wrench space
 //                              for 3-4 legs and for contact schedules), J' f, 60-float action row.
-//   rg_qp_fused_retry_kernel / rg_qp_admm_tile_kernel<..., true>
-//                              exact dual active-set re-solve of the robots ADMM left unconverged (RG_SOLVER_AUTO),
-//                              or of every robot (RG_SOLVER_ACTIVE_SET).  The same exact bodies also serve two side
-//                              streams: the audit lane (converged robots re-solved and compared, rg_qp_common.inc) and
-//                              the direct lists (persistently hard robots solved next to the ADMM launch).
+//                              RG_SOLVER_HYBRID (default, horizon 10): one- and two-leg robots are solved EXACTLY in this
+//                              launch by a one-wave dual active-set body warm-started from the robot's previous working set
+//                              (rg_qp_exact_kernel.inc); three and four legs keep the wrench-space ADMM body.
+//   rg_qp_resolve_kernel / rg_qp_sched_retry_kernel
+//                              exact dual active-set re-solve (one body per kernel) of the robots the launch above could
+//                              not finish: ADMM at its iteration cap, an exact working set that overflowed.  The same
+//                              kernel also serves two side streams: the audit lane (converged ADMM robots re-solved and
+//                              compared, rg_qp_common.inc) and the direct lists (persistently hard robots solved next to
+//                              the ADMM launch).
 // Every accepted configuration has a GPU-tested instantiation; anything else is rejected by rg_mpc_create.
 // No MFMA: the per-robot blocks are 6..12 wide and every robot has its own operands.
 #include "rg_mpc_dev.h"
@@ -21,6 +25,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -29,6 +34,7 @@
 #include "rg_qp_common.inc"
 #include "rg_qp_tile_kernel.inc"
 #include "rg_qp_wrench_kernel.inc"
+#include "rg_qp_exact_kernel.inc"
 #include "rg_qp_sched_kernel.inc"
 #include "rg_qp_fused_kernel.inc"
 
@@ -49,6 +55,8 @@ __global__ void rg_reset_kernel(const DevCfg *__restrict__ c, DevState st, const
   for (int a = 0; a < 3; a++) { st.fsum[a * B + b] = 0.0; st.fcorr[a * B + b] = 0.0; }
   st.swing_valid[b] = 0;
   st.warm_key[b] = -1;
+  st.hard[b] = 0;    // a reset robot is a fresh robot: ADMM first, no direct routing, no cost prediction from before
+  st.iters[b] = 0;
 }
 
 // RobotMotorModel.convert_to_torque HYBRID (reference model/robots/simple_motor.py:128-140), for S consecutive
@@ -87,7 +95,8 @@ struct rg_mpc_handle {
   std::vector<hipEvent_t> ev;   // RG_PROF_EV events per profiled step
   int prof_max = 0, prof_n = 0, prof_stride = 1;   // events are recorded on every prof_stride-th step
   long long tick = 0;
-  bool fused = false;               // ADMM plans (RG_SOLVER_ADMM / RG_SOLVER_AUTO): one launch for all stance-leg counts
+  bool fused = false;               // one QP launch for all stance-leg counts, work order = the front kernel's cost classes (every plan except exact + contact schedule)
+  bool exact12 = false;             // ... in which one- and two-leg robots run the exact active-set body (RG_SOLVER_HYBRID / RG_SOLVER_ACTIVE_SET, horizon 10, constant contacts)
   int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO: robots ADMM left unconverged are re-solved exactly
   int retry_max_nc = 0;             // ... for robots with up to this many stance legs
@@ -138,12 +147,13 @@ struct AuditLane {
   hipEvent_t front_done = nullptr, direct_done = nullptr;
 };
 static std::mutex g_lane_mu;
-static std::vector<AuditLane> g_lane_pool[64];   // per device
+static std::map<int, std::vector<AuditLane>> g_lane_pool;   // per device
 
 static hipError_t audit_lane_acquire(int device, AuditLane *lane) {
   {
     std::lock_guard<std::mutex> lk(g_lane_mu);
-    if (device >= 0 && device < 64 && !g_lane_pool[device].empty()) { *lane = g_lane_pool[device].back(); g_lane_pool[device].pop_back(); return hipSuccess; }
+    std::vector<AuditLane> &pool = g_lane_pool[device];
+    if (!pool.empty()) { *lane = pool.back(); pool.pop_back(); return hipSuccess; }
   }
   // lowest priority: the exact re-solves fill the gaps the tick's own launches leave (the tail of the ADMM launch), they must
   // not compete with them for CUs
@@ -159,6 +169,14 @@ static hipError_t audit_lane_acquire(int device, AuditLane *lane) {
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&lane->direct, hipStreamNonBlocking, prio_high);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&lane->front_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&lane->direct_done, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    // a half-built lane is neither handed out nor destroyed (destroying is what the pool exists to avoid): it is parked where
+    // it stays reachable, and the handle's create fails
+    static std::vector<AuditLane> graveyard;
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    graveyard.push_back(*lane);
+    *lane = AuditLane();
+  }
   return e;
 }
 static void audit_lane_release(int device, const AuditLane &lane) {
@@ -166,7 +184,7 @@ static void audit_lane_release(int device, const AuditLane &lane) {
   (void)hipStreamSynchronize(lane.stream);
   (void)hipStreamSynchronize(lane.direct);
   std::lock_guard<std::mutex> lk(g_lane_mu);
-  if (device >= 0 && device < 64) g_lane_pool[device].push_back(lane);
+  g_lane_pool[device].push_back(lane);
 }
 
 #define RG_PROF_EV 11  // [0] step start, [1] front end, [2+2k],[3+2k] QP nc=k+1 start/end, [10] step end
@@ -197,13 +215,13 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
   if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
   if (!(c->accel_cos2 > 0 && c->accel_cos2 < 1) || !(c->accel_rmin > 0 && c->accel_rmin < c->accel_rmax && c->accel_rmax < 1) || !(c->accel_rate_cap > 0 && c->accel_rate_cap < 1)) { err = "extrapolation thresholds out of range: 0 < accel_cos2 < 1, 0 < accel_rmin < accel_rmax < 1, 0 < accel_rate_cap < 1"; return RG_MPC_ERR_INVALID; }
-  if (c->audit_k < 0 || c->audit_k * RG_AUDIT_PERIOD * 2 > RG_AUDIT_SLOTS || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
-  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
+  if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / (2 * RG_AUDIT_PERIOD) || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
+  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0 || !(c->admm_rho34_scale > 0 && c->admm_rho34_scale <= 10)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
-  if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
+  if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO && c->solver != RG_SOLVER_HYBRID) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
   if (c->solver == RG_SOLVER_ACTIVE_SET && c->horizon != 10) { err = "RG_SOLVER_ACTIVE_SET (every robot solved exactly) needs horizon 10"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho > 0) || c->admm_iters < 1 || !(c->admm_relax > 0 && c->admm_relax < 2) || !(c->admm_tol >= 0) || (c->admm_tol > 0 && c->admm_check < 1)) { err = "bad ADMM parameters"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 12; i++) if (!(c->motor_dir[i] == 1.0 || c->motor_dir[i] == -1.0)) { err = "motor_dir must be +-1"; return RG_MPC_ERR_INVALID; }
@@ -243,7 +261,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   for (int i = 0; i < 12; i++) d->tip[i] = c->toe_xyz[i] + c->toe_com[i];
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
-  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->admm_switch = c->admm_switch; d->admm_extrap = c->admm_extrap > 0.0 ? c->admm_extrap : INFINITY;
+  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->rho34_scale = c->admm_rho34_scale; d->admm_switch = c->admm_switch; d->admm_extrap = c->admm_extrap > 0.0 ? c->admm_extrap : INFINITY;
   d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
@@ -272,7 +290,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,rg_qp_admm_tile_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_resolve_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -282,16 +300,21 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   *out = nullptr;
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
-  // Launch plans.  ADMM solvers: front -> fused QP launch -> exact re-solves (RG_SOLVER_AUTO).  RG_SOLVER_ACTIVE_SET
-  // (horizon 10): front -> one exact launch per stance-leg count.
-  h->fused = cfg->solver != RG_SOLVER_ACTIVE_SET;
-  h->auto_retry = cfg->solver == RG_SOLVER_AUTO;
-  // exact re-solve bodies: every stance-leg count at horizon 10 (force space; under a contact schedule the absent blocks
-  // are identity rows); at horizon 20 one and two legs in force space, three and four legs and any contact schedule in
-  // wrench space (rg_qp_sched_retry_kernel).  Every robot ADMM leaves unconverged has an exact pass behind it.
+  // Launch plans: front -> one QP launch over all stance-leg counts -> exact re-solve launch (normally empty).
+  //   RG_SOLVER_HYBRID (horizon 10, constant contacts): exact body for one / two legs, wrench-space ADMM for three / four;
+  //     at horizon 20 or with a contact schedule it is RG_SOLVER_AUTO (those QP bodies have no one-wave exact form).
+  //   RG_SOLVER_ACTIVE_SET (horizon 10): the same launch with three / four legs handed to the exact re-solve launch; with
+  //     a contact schedule every robot goes there directly (front kernel plan 0: list = stance-leg bin).
+  const bool as_only = cfg->solver == RG_SOLVER_ACTIVE_SET;
+  h->exact12 = (cfg->solver == RG_SOLVER_HYBRID || as_only) && cfg->horizon == 10 && !cfg->contact_lookahead;
+  h->fused = !(as_only && cfg->contact_lookahead);
+  h->auto_retry = cfg->solver != RG_SOLVER_ADMM;
+  // exact re-solve body behind every robot the QP launch hands on: horizon 10 -- the four-leg force-space active-set body
+  // with absent (step, leg) blocks taken out (any stance-leg count, any schedule); horizon 20 -- the wrench-space one
   h->retry_max_nc = h->auto_retry ? 4 : 0;
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   h->hcfg.plan = h->fused ? 1 : 0;
+  h->hcfg.exact12 = h->exact12 ? (cfg->solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0;
   if (rc) { g_create_err = h->err; delete h; return rc; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_err = "no HIP device available"; delete h; return RG_MPC_ERR_NO_DEVICE; }
@@ -312,11 +335,14 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
   AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N);
   if (cfg->warm_start) { AL(h->st.warm_z, B * RG_WARM_N); AL(h->st.warm_y, B * RG_WARM_N); }
+  if (cfg->warm_start && h->exact12) { AL(h->st.ws_ids, B * RG_WS_MAX); AL(h->st.ws_cnt, B); }
   AL(h->st.warm_key, B); AL(h->st.bins, RG_NLISTS * B); AL(h->counts2, 2 * RG_NCOUNTS); AL(h->st.iters, B); AL(h->st.ncs, B);
   h->st.counts = h->counts2; h->st.counts_next = h->counts2 + RG_NCOUNTS;
   AL(h->idx_dev, B); AL(h->t0_dev, B);
   AL(h->st.hard, B);
-  h->direct_on = h->fused && h->auto_retry && cfg->horizon == 10 && !cfg->contact_lookahead;
+  // direct lists (work lists 1..4 read by rg_qp_resolve_kernel): persistently hard robots of the ADMM bodies, and -- exact
+  // solver with a contact schedule -- every robot
+  h->direct_on = h->auto_retry && cfg->horizon == 10 && (!cfg->contact_lookahead || !h->fused);
   if (h->direct_on) {
     CR(hipHostMalloc((void **)&h->hint_host, 64, hipHostMallocDefault));
     *h->hint_host = 0;
@@ -325,7 +351,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
     h->st.hint_host = (int *)dp;
     AL(h->st.hint_dev, 1);
   }
-  h->audit_on = h->fused && cfg->audit_k > 0;
+  h->audit_on = h->fused && cfg->audit_k > 0 && !as_only;   // the audit re-solves CONVERGED ADMM robots; the exact plan has none
   if (h->audit_on || h->direct_on) {
     AuditLane lane;
     CR(audit_lane_acquire(device, &lane));
@@ -461,7 +487,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // host runs ticks ahead of the GPU, so this is a hint, and both paths are correct whatever it says)
   h->st.direct_on = h->direct_on ? 1 : 0;
   h->st.tick = (int)(h->steps & 0x7fffffff);
-  const bool direct_now = h->direct_on && *(volatile int *)h->hint_host > 0;
+  const bool direct_now = h->direct_on && h->fused && *(volatile int *)h->hint_host > 0;
   h->steps++;
   hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
@@ -471,47 +497,32 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (direct_now) {
     HIPCHK(h, hipEventRecord(h->front_done, s));
     HIPCHK(h, hipStreamWaitEvent(h->direct_stream, h->front_done, 0));
-    HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->direct_stream, RETRY_DIRECT));
+    HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, h->direct_stream, RETRY_DIRECT));
     HIPCHK(h, hipEventRecord(h->direct_done, h->direct_stream));
     h->direct_launches++;
   }
+  // one QP launch over all stance-leg counts, then the (normally empty) exact re-solve lists
+  // four events per profiled step: [0] start, [1] front end, [3] QP launch end, [5] re-solve end
+  // (a contact schedule puts every robot on the schedule body: its own launch, same work lists; the exact solver with a
+  // contact schedule has no QP launch of its own: the front kernel's stance-leg bins are the re-solve launch's direct lists)
   if (h->fused) {
-    // ADMM plans: one launch over all stance-leg counts, then the (normally empty) exact re-solve lists
-    // four events per profiled step: [0] start, [1] front end, [3] fused end, [5] re-solve end
-    // (a contact schedule puts every robot on the schedule body: its own launch, same work lists)
     if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
-    else HIPCHK(h, launch_qp_fused_any(H, h->dcfg, h->st, dout, B, h->cu_count, s));
-    if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
-    if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));
-    if (direct_now) HIPCHK(h, hipStreamWaitEvent(s, h->direct_done, 0));   // the direct robots' actions are part of this tick
-    if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, s, direct_now ? RETRY_LISTS : RETRY_ALL));
-    else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
-    if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
-    if (ring >= 0) {
-      // the same exact bodies, in audit mode, over the captured records: side stream, ordered after the ADMM launch only
-      HIPCHK(h, hipStreamWaitEvent(h->audit_stream, h->audit_fused[ring], 0));
-      if (H == 10) {
-        // three / four legs (and every robot of a contact schedule, entries of "four legs") on the 256-lane bodies, one / two
-        // legs on the one-wave exact bodies: an exact solve then keeps one SIMD busy, not a whole CU
-        HIPCHK(h, launch_qp_fused_retry_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, RETRY_AUDIT34));
-        HIPCHK(h, (launch_qp_tile_exact<2, 10, 8, 3>(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, false, h->st.audit_k + h->st.audit_k / 4)));
-        HIPCHK(h, (launch_qp_tile_exact<1, 10, 4, 3>(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, false, 4)));
-      } else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
-      HIPCHK(h, hipEventRecord(h->audit_done[ring], h->audit_stream));
-      h->audit_inflight[ring] = true;
-    }
-    return RG_MPC_OK;
+    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->dcfg, h->st, dout, B, h->cu_count, s));
   }
-  // RG_SOLVER_ACTIVE_SET: one exact launch per stance-leg count
-  for (int nc = 1; nc <= 4; nc++) {
-    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc], s));
-    hipError_t lerr;
-    if (!launch_qp_tile_dispatch(nc, H, h->dcfg, h->st, dout, B, h->cu_count, s, &lerr, 1)) { h->err = "step: no exact solver body for this (horizon, stance legs)"; return RG_MPC_ERR_INVALID; }
-    HIPCHK(h, lerr);
-    if (pev) HIPCHK(h, hipEventRecord(pev[2 * nc + 1], s));
+  if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
+  if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));
+  if (direct_now) HIPCHK(h, hipStreamWaitEvent(s, h->direct_done, 0));   // the direct robots' actions are part of this tick
+  if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, s, direct_now ? RETRY_LISTS : RETRY_ALL));
+  else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
+  if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
+  if (ring >= 0) {
+    // the same exact body, in audit mode, over the captured records: side stream, ordered after the ADMM launch only
+    HIPCHK(h, hipStreamWaitEvent(h->audit_stream, h->audit_fused[ring], 0));
+    if (H == 10) HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, RETRY_AUDIT));
+    else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
+    HIPCHK(h, hipEventRecord(h->audit_done[ring], h->audit_stream));
+    h->audit_inflight[ring] = true;
   }
-  if (pev) HIPCHK(h, hipEventRecord(pev[10], s));
-  if (pev) h->prof_n++;
   return RG_MPC_OK;
 }
 
@@ -529,9 +540,8 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
 }
 
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
-  if (h && h->fused && h->cfg.contact_lookahead) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_sched_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
-  if (h && h->fused) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_fused_kernel,rg_qp_fused_retry_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_fused_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
-  return "rg_front_kernel,qp launches nc=1,qp launches nc=2,qp launches nc=3,qp launches nc=4,step_total";
+  if (h && h->cfg.contact_lookahead) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_sched_kernel,rg_qp_resolve_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
+  return (!h || h->cfg.horizon == 10) ? "rg_front_kernel,rg_qp_fused_kernel,rg_qp_resolve_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_fused_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
 }
 
 // robots per stance-leg count of the last tick, from the per-robot record (the work lists may be cost classes)
@@ -560,14 +570,9 @@ int rg_mpc_profile_end(rg_mpc_handle *h, float *avg_ms6, int32_t *robots5, void 
     hipEvent_t *e = &h->ev[(size_t)k * RG_PROF_EV];
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[1])); acc[0] += ms;
-    if (h->fused) {
-      HIPCHK(h, hipEventElapsedTime(&ms, e[1], e[3])); acc[1] += ms;
-      HIPCHK(h, hipEventElapsedTime(&ms, e[3], e[5])); acc[2] += ms;
-      HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[5])); acc[5] += ms;
-      continue;
-    }
-    for (int nc = 1; nc <= 4; nc++) { HIPCHK(h, hipEventElapsedTime(&ms, e[2 * nc], e[2 * nc + 1])); acc[nc] += ms; }
-    HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[10])); acc[5] += ms;
+    HIPCHK(h, hipEventElapsedTime(&ms, e[1], e[3])); acc[1] += ms;
+    HIPCHK(h, hipEventElapsedTime(&ms, e[3], e[5])); acc[2] += ms;
+    HIPCHK(h, hipEventElapsedTime(&ms, e[0], e[5])); acc[5] += ms;
   }
   for (int j = 0; j < 6; j++) avg_ms6[j] = n > 0 ? (float)(acc[j] / n) : 0.f;
   if (robots5) { int tmp[5]; int r_ = host_bin_counts(h, tmp); if (r_) return r_; for (int k = 0; k < 5; k++) robots5[k] = tmp[k]; }

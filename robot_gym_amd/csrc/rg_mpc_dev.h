@@ -56,8 +56,10 @@ struct DevCfg {
   double admm_prim_tol;  // 10 * admm_abs_tol: largest |x - z| (unprojected vs projected force) accepted at convergence
   int admm_check, lookahead;
   int solver, warm;
+  int exact12;           // 1: one- and two-leg robots run the exact active-set body (their st.iters counts applications of G); 2: every robot does
   int plan, admm_switch; // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*); admm_switch: first-stage iterations
   double rho2;           // second-stage ADMM rho (0 = single stage)
+  double rho34_scale;    // first-stage rho of the wrench-space ADMM body (three / four legs, horizon 10) = rho x this
   double accel_k[4];     // thresholds of the extrapolation test {accel_cos2 0.9, accel_rmax 0.98, accel_rmin 0.5, accel_rate_cap 0.999}
                          // (rg_mpc_config): read from here (scalar loads) because as literals they were materialised in VGPR pairs at
                          // kernel entry and spilled to scratch by every workgroup
@@ -80,7 +82,9 @@ struct DevState {
   float *cmd;           // [3][B] rg_mpc_set_command copy
   double *rec;          // [B][RG_REC_N]
   float *warm_z, *warm_y;   // [B][RG_WARM_N] previous-tick ADMM iterate (warm start); float32: it is only a starting point
-  int *warm_key;        // [B] contact mask the stored iterate belongs to (-1 = none)
+  int *warm_key;        // [B] contact mask the stored iterate / working set belongs to (-1 = none)
+  unsigned char *ws_ids; // [B][RG_WS_MAX] exact body: constraint ids of the robot's working set at the end of the previous tick
+  int *ws_cnt;          // [B] ... and their number
   int *bins;            // [RG_NLISTS][B] work lists (see RG_NLISTS)
   int *counts;          // [RG_NCOUNTS] list lengths and failure count (see RG_NCOUNTS)
   int *ncs;             // [B] stance-leg count of each robot in the last tick

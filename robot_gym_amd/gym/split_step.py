@@ -1,53 +1,61 @@
-"""The two halves of the reference's env step() as mixins, for envs stepped by MPCVecEnv.
+"""One-pass stepping for envs inside MPCVecEnv, without restating any env code.
 
-MPCVecEnv makes ONE batched controller call per tick, in the middle of every env's step.  An env that offers
-    pre_step(action, **kwargs) -> (command, kwargs)               everything before controller.update_controller_params
-    post_step(motor_action, **kwargs) -> (obs, reward, done, info)  from simulation.ApplyStepAction on
-runs its pre-controller code once per tick; an env that does not is stepped twice (robot_gym_amd/gym/vec_env.py), which
-repeats whatever that code does besides deriving the command -- GoEnv(show_plot=True)._update_plot, the camera writes of
-parse_equipment_ui_params, RNG draws of a user env.  Use:
+MPCVecEnv makes ONE batched controller call per tick, in the middle of every env's step().  The reference's task envs end
+their own step() in `super(TaskEnv, self).step(action, **kwargs)` (gym/envs/go_to/go_env.py:296 -> RobotGymEnv.step,
+gym/robot_gym_env.py:117-129, which is where the controller is asked for its action).  `one_pass(TaskEnv, BaseEnv)` builds
 
-    class BatchedRobotGymEnv(RobotGymEnvSplitStep, RobotGymEnv): pass
-    class BatchedGoEnv(GoEnvSplitStep, GoEnv): pass
+    class _Intercept(BaseEnv): ...            # sits AFTER the task env in the MRO
+    class OnePassTaskEnv(TaskEnv, _Intercept)
 
-The bodies restate the statement order of the reference methods they split (cited per line); step() itself is untouched, so
-the same class still works alone with the batch-1 MPCController.
+so that the task env's pre-controller code (action clipping, standing action on target, camera hooks, plots -- whatever it
+is, none of it is known here) runs exactly ONCE per tick: the call it ends in lands in `_Intercept.step`, which records
+`(action, kwargs)`, hands the command to the env's slot controller and suspends (phase 1); phase 3 calls `BaseEnv.step` itself
+with the recorded arguments and the batched action row.  Outside MPCVecEnv (a single env with the batch-1 MPCController)
+the interceptor is a pass-through.
+
+    BatchedGoEnv = one_pass(GoEnv, RobotGymEnv)
+    envs = [BatchedGoEnv(..., controller_class=BatchSlotController) for _ in range(B)]
+
+An env class that is stepped without this (or without its own pre_step / post_step pair) goes through MPCVecEnv's two-pass
+path: its whole step() runs twice, which is only right when the code in front of the controller call is repeatable.
 """
-import numpy as np
+from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController, StepSuspended
 
 
-class RobotGymEnvSplitStep:
-    """reference gym/robot_gym_env.py:117-129, cut at the controller call (:120-121)."""
-
-    def pre_step(self, action, **kwargs):
-        return action, kwargs
-
-    def post_step(self, motor_action, **kwargs):
-        self._simulation.ApplyStepAction(motor_action)                 # :122
-        if "update_equip" in kwargs:
-            self._simulation.robot.update_equipment()                  # :123-124
-        observation = self.get_observation()                           # :125
-        reward = self.reward()                                         # :126
-        done, info = self.termination()                                # :127
-        return np.array(observation), reward, done, info               # :129
+def _slot_of(env):
+    sim = getattr(env, "simulation", None) or getattr(env, "_simulation", None)
+    ctl = getattr(sim, "controller", None)
+    return ctl if isinstance(ctl, BatchSlotController) else None
 
 
-class GoEnvSplitStep(RobotGymEnvSplitStep):
-    """reference gym/envs/go_to/go_env.py:272-296 in front of RobotGymEnv.step."""
+def one_pass(task_env_cls, base_env_cls=None):
+    """Subclass of `task_env_cls` whose step() suspends at `base_env_cls.step` -- the class whose step() asks the controller
+    for its action; default: the task env's direct base -- while MPCVecEnv collects commands, and resumes from there."""
+    if base_env_cls is None:
+        base_env_cls = task_env_cls.__mro__[1]
+    if not (isinstance(base_env_cls, type) and issubclass(task_env_cls, base_env_cls) and "step" in vars(base_env_cls)):
+        raise TypeError(f"{base_env_cls!r} must be a base of {task_env_cls.__name__} that defines step()")
 
-    def pre_step(self, action, **kwargs):
-        if self._debug and not self.simulation.read_ui_parameters(self._ui) and not self._policy:
-            action = self._read_inputs()                               # :273-275 UI input overrides the agent
-        if self._debug and (self.simulation.read_ui_parameters(self._ui) or self._policy):
-            action = max(0, min(action[0], 0.35)), max(-0.4, min(action[1], 0.4))   # :278-280
-        if self._debug and self.parse_equipment_ui_params():           # :283-289 follower camera
-            pos_x, pos_y = self._follower.cam_pos_point.get_xy()
-            target_x, target_y = self._follower.cam_target_point.get_xy()
-            self.simulation.robot.get_default_camera().position = pos_x, pos_y, 0.095
-            self.simulation.robot.get_default_camera().target = target_x, target_y, 0.0
-            kwargs = {"update_equip": True}
-        if self._on_target():
-            action = self.simulation.controller.get_standing_action()  # :291-292
-        if self._show_plot:
-            self._update_plot()                                        # :294-295 -- once per tick
-        return action, kwargs
+    class _Intercept(base_env_cls):
+        def step(self, action, **kwargs):
+            ctl = _slot_of(self)
+            if ctl is None or ctl.phase != "capture":
+                return super().step(action, **kwargs)
+            self._intercepted_step = (action, kwargs)
+            ctl.update_controller_params(action)   # what base_env_cls.step does first; repeated, unchanged, on resume
+            raise StepSuspended()
+
+        def resume_step(self, action_row):
+            """Phase 3: base_env_cls.step with the arguments the task env's step() ended in and the batched action row."""
+            action, kwargs = self._intercepted_step
+            ctl = _slot_of(self)
+            ctl.begin_replay(action_row)
+            try:
+                return base_env_cls.step(self, action, **kwargs)
+            finally:
+                ctl.phase, ctl.action = "idle", None
+                self._intercepted_step = None
+
+    _Intercept.__name__ = f"_Intercept{base_env_cls.__name__}"
+    bases = (_Intercept,) if task_env_cls is base_env_cls else (task_env_cls, _Intercept)
+    return type(f"OnePass{task_env_cls.__name__}", bases, {"__doc__": f"{task_env_cls.__name__} stepped in one pass by MPCVecEnv (split_step.one_pass)."})

@@ -15,13 +15,14 @@ camera hook (gym/envs/go_to/go_env.py:272-296) is not re-implemented here.  Ever
      two-half protocol
          pre_step(action, **kwargs) -> (command, kwargs)      everything before controller.update_controller_params
          post_step(motor_action, **kwargs) -> (obs, reward, done, info)   from simulation.ApplyStepAction on
-     (robot_gym_amd/gym/split_step.py has the two halves of the reference's RobotGymEnv.step and GoEnv.step as mixins) run
-     their pre-controller code ONCE.  Any other env is driven through its unmodified step() twice: the first pass is
-     unwound at the controller call (`get_action` raises StepSuspended, caught here), the second pass gets the action.
-     Code in front of the controller call therefore runs twice for such an env -- harmless when it only derives the
-     command (the slot controller refuses a second pass that derives a different one, before anything is applied), NOT
-     harmless when it has side effects of its own (GoEnv(show_plot=True)._update_plot, RNG draws, counters): give those
-     envs the mixin.
+     run their pre-controller code ONCE, and so do envs built by `split_step.one_pass(TaskEnv, BaseEnv)`: a generic
+     interceptor placed after the task env in the MRO suspends the step where the task env's own step() calls
+     `super().step(action, **kwargs)` and later resumes `BaseEnv.step` with those arguments -- no env code is restated.
+     Any other env is driven through its unmodified step() twice: the first pass is unwound at the controller call
+     (`get_action` raises StepSuspended, caught here), the second pass gets the action.  Code in front of the controller
+     call therefore runs twice for such an env -- harmless when it only derives the command (the slot controller refuses
+     a second pass that derives a different one, before anything is applied), NOT harmless when it has side effects of
+     its own (GoEnv(show_plot=True)._update_plot, RNG draws, counters): build those envs with `one_pass`.
   2. the wrapper gathers every robot's state, its own clock and its command into ONE pinned slab, uploads it once, runs
      rg_mpc_step for all envs and downloads the [B, 60] action slab once.  Pending per-env resets (the env's
      Simulation.reset() -> controller.reset()) are applied first, each with that env's own clock value.
@@ -79,6 +80,7 @@ class _EnvGroup:
                 raise TypeError(f"env {lo + b}: simulation.controller is {type(ctl).__name__}; MPCVecEnv needs envs built with "
                                 "controller_class=BatchSlotController (one slot of the batched GPU controller per env)")
         self.split = [hasattr(env, "pre_step") and hasattr(env, "post_step") for env in self.envs]
+        self.one_pass = [not sp and hasattr(env, "resume_step") for sp, env in zip(self.split, self.envs)]   # split_step.one_pass classes
         self.jacobian_fn = jacobian_fn or _default_jacobian
         self.offsets = np.array([cfg.vx_offset, cfg.vy_offset, cfg.wz_offset], dtype=np.float32).reshape(3, 1)
         self.kwargs = [None] * len(self.envs)
@@ -132,6 +134,9 @@ class _EnvGroup:
             if self.split[b]:
                 transitions.append(env.post_step(np.array(rows[b], dtype=np.float32), **(self.kwargs[b] or {})))
                 continue
+            if self.one_pass[b]:
+                transitions.append(env.resume_step(rows[b]))   # BaseEnv.step with the arguments the task env's step() ended in
+                continue
             ctl.begin_replay(rows[b])
             try:
                 transitions.append(env.step(a))
@@ -178,6 +183,8 @@ def _worker_main(conn, constructors, lo, batch, shm_state, shm_act, cfg, jacobia
                 group.pre(actions)
                 conn.send((_READY, group.gather()))
                 message, _ = conn.recv()
+                if message == _CLOSE:   # the parent gave up on this tick (another slice failed): leave without finishing it
+                    break
                 if message != _ACT:
                     raise KeyError(f"expected the action message, got {message}")
                 # one message of stacked arrays per slice, not n pickled tuples (the parent's serial unpickling of 4096 small
@@ -280,6 +287,7 @@ class MPCVecEnv:
             self._group = _EnvGroup(self._envs, 0, views, self._state.host_clock.numpy(), self._state.host_cmd.numpy(), self.cfg, jacobian_fn)
             self._slots = self._group.slots
         self.batched_calls = 0
+        self._broken = None   # set when a tick failed half-way: the batch is then in no defined state
 
     @staticmethod
     def _check_slots(envs):
@@ -300,7 +308,7 @@ class MPCVecEnv:
     def __getattr__(self, name):
         """Forward unimplemented attributes to the first env (reference batch_env.py:52-61 forwards every name; with worker
         processes the request goes to the first worker, like ExternalProcess.__getattr__, wrappers.py:343-356)."""
-        if name in ("_envs", "_blocking", "_workers", "_shm", "_group", "_batch"):   # not set yet: no recursion during __init__
+        if name in ("_envs", "_blocking", "_workers", "_shm", "_group", "_batch", "_broken"):   # not set yet: no recursion during __init__
             raise AttributeError(name)
         if self._blocking:
             return getattr(self._envs[0], name)
@@ -329,11 +337,35 @@ class MPCVecEnv:
         """action: batch of per-env actions (whatever the envs' action_space holds, e.g. (vx, wz)).
         Returns stacked (observ, reward, done, info) like reference batch_env.py:63-93."""
         actions = action
+        if self._broken is not None:
+            raise RuntimeError(f"this MPCVecEnv is unusable: an earlier step() failed half-way ({self._broken}); build a new one")
         if len(actions) != self._batch:
             raise ValueError(f"expected {self._batch} actions, got {len(actions)}")
         for index, a in enumerate(actions):
             if not self._action_space.contains(a):
                 raise ValueError("Invalid action at index {}: {}".format(index, a))
+        # An exception from here on leaves the batch half-stepped -- some envs have run their pre-controller code or applied
+        # their action, the batched controller may have advanced every robot, workers may be blocked waiting for the action
+        # message -- so it is fatal for the whole wrapper: the workers are shut down and every later step() raises.
+        try:
+            return self._step_unchecked(actions)
+        except BaseException as e:
+            self._broken = f"{type(e).__name__}: {e}".splitlines()[0][:200]
+            self._abort_workers()
+            raise
+
+    def _abort_workers(self):
+        for w in self._workers:
+            try:
+                w.conn.send((_CLOSE, None))
+            except (IOError, OSError, ValueError):
+                pass
+        for w in self._workers:
+            w.process.join(timeout=2)
+            if w.process.is_alive():
+                w.process.terminate()
+
+    def _step_unchecked(self, actions):
         if self._blocking:
             self._group.pre(actions)
             rows = self._controller_call(self._group.gather())

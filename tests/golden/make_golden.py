@@ -388,8 +388,8 @@ def gen_env_step():
     from robot_gym_amd import synthetic
     from tests.fake_envs import StubRobot, FakeSimulation, Box
 
-    def make_env(sim, on_target=False, camera=False, log=None):
-        env = object.__new__(GoEnv)            # no __init__: that one builds a PyBullet world
+    def make_env(sim, on_target=False, camera=False, log=None, cls=None):
+        env = object.__new__(cls or GoEnv)     # no __init__: that one builds a PyBullet world
         env._simulation = sim
         env._debug, env._policy, env._ui, env._show_plot = True, True, None, False
         env._on_target = lambda: on_target
@@ -474,6 +474,32 @@ def gen_env_step():
         ticks.append({"obs": np.asarray(o).tolist(), "reward": np.asarray(r).tolist(), "done": np.asarray(d).tolist(),
                       "applied_row_head": [e.simulation.applied[-1][:4].round(6).tolist() for e in envs],
                       "equipment_updates": [e.simulation.robot.equipment_updates for e in envs]})
+    # ---- (2b) the same reference class stepped in ONE pass: split_step.one_pass(GoEnv, RobotGymEnv) puts a generic interceptor
+    # after GoEnv in the MRO; GoEnv.step's own code in front of the controller call -- here with show_plot on and a counting
+    # _update_plot (go_env.py:294-295) -- then runs once per tick, where the two-pass path above runs it twice
+    from robot_gym_amd.gym.split_step import one_pass
+    OnePassGoEnv = one_pass(GoEnv, RobotGymEnv)
+    calls_b, calls = calls, []
+    envs1, plots = [], []
+    for b, kw in enumerate(({}, {"on_target": True}, {"camera": True})):
+        sim = FakeSimulation(StubRobot(cfg, state, b), BatchSlotController, config=cfg)
+        sim.read_ui_parameters = lambda ui: False
+        sim.robot.get_default_camera = lambda: cam
+        env = make_env(sim, cls=OnePassGoEnv, **kw)
+        env._show_plot = True
+        counter = [0]
+        env._update_plot = (lambda c: (lambda: c.__setitem__(0, c[0] + 1)))(counter)
+        plots.append(counter)
+        envs1.append(env)
+    venv1 = vec_env.MPCVecEnv(envs1, config=cfg)
+    ticks1 = []
+    for k in range(2):
+        o, r, d, i = venv1.step(actions)
+        ticks1.append({"obs": np.asarray(o).tolist(), "reward": np.asarray(r).tolist(), "done": np.asarray(d).tolist(),
+                       "applied_row_head": [e.simulation.applied[-1][:4].round(6).tolist() for e in envs1],
+                       "equipment_updates": [e.simulation.robot.equipment_updates for e in envs1],
+                       "update_plot_calls": [c[0] for c in plots]})
+    one_pass_calls, calls = calls, calls_b
     # ---- (3) the real Simulation clock and action-repeat loop (core/simulation.py:123-127,141-142,170-179) ----
     from robot_gym.core.simulation import Simulation
     sim = object.__new__(Simulation)
@@ -491,6 +517,7 @@ def gen_env_step():
     out["simulation_clock"] = {"after_each_tick_hex": [float(c).hex() for c in clock], "sim_steps_per_tick": n_apply // 12,
                                "reset_calls_controller_reset": applied.count("controller.reset"), "after_reset": sim.GetTimeSinceReset()}
     out["vec_env"] = {"actions": actions.tolist(), "ticks": ticks, "batched_calls": calls, "offsets": [cfg.vx_offset, cfg.vy_offset, cfg.wz_offset]}
+    out["vec_env_one_pass"] = {"mro": [k.__name__ for k in OnePassGoEnv.__mro__[:4]], "ticks": ticks1, "batched_calls": one_pass_calls}
     with open(os.path.join(OUT, "env_step.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 
@@ -550,6 +577,22 @@ def gen_adapter():
             "MOTOR_OFFSET": motor.MOTOR_OFFSET.tolist(),
         }
         out["robots"][robot_name] = rec
+    # UI glue (mpc_controller.py:68-81), the reference's own statics driven with a recording stub client -- the same stub the
+    # host test hands this repo's plugin classes (tests/test_host_logic.py::test_ui_glue_of_the_controller_plugins)
+    class Client:
+        def __init__(self): self.log, self.values = [], {}
+        def addUserDebugParameter(self, name, lo, hi, start):
+            self.log.append(["addUserDebugParameter", name, lo, hi, start])
+            self.values[len(self.values) + 10] = 0.25 * (len(self.values) + 1)
+            return len(self.values) + 9
+        def readUserDebugParameter(self, handle):
+            self.log.append(["readUserDebugParameter", handle])
+            return self.values[handle]
+    client = Client()
+    ui = ref_mpc.MPCController.setup_ui_params(client)
+    vals = ref_mpc.MPCController.read_ui_params(client, ui)
+    out["ui_glue"] = {"ui_handles": list(ui), "ui_values": [float(v) for v in vals], "client_log": client.log,
+                      "standing_action": list(ref_mpc.MPCController.get_standing_action())}
     from robot_gym.core import sim_constants
     out["sim_constants"] = {"ACTION_REPEAT": sim_constants.ACTION_REPEAT, "SIMULATION_TIME_STEP": sim_constants.SIMULATION_TIME_STEP}
     from robot_gym.util.cli import flags

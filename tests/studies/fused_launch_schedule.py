@@ -1,32 +1,64 @@
-"""Study (GPU, needs a library built with per-robot wall_clock64 stamps written into the optional grf output -- see DESIGN.md
-section 5 -- as scratch/librg_mpc_stamp.so): the actual schedule of the fused launch on the 2048 wave slots.  Outcome: every
-slot gets exactly two jobs; the launch ends at (longest first-round job) + (cheapest job), 112 + 58 us, against 134 us of
-mean slot load."""
+"""Study (GPU; needs the measurement build `make -C robot_gym_amd/csrc stamp`): the actual schedule of the QP launch on the
+2048 wave slots, from per-robot start / end clock stamps (100 MHz).  Per solver plan: kernel span, mean slot load, and the
+job durations by stance-leg count and solver work (iterations).
+    python tests/studies/fused_launch_schedule.py [batch] ['{"solver": 2}' ...]"""
+import json
+import os
+import sys
 
-import sys, os
-os.environ["RG_MPC_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librg_mpc_stamp.so")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch, json
-import bench
-from robot_gym_amd.core.config import MPCConfig
-from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
-B = 4096
-torch.cuda.set_device(0); device = torch.device("cuda", 0)
-over = json.loads(os.environ.get("RG_OVER", "{}"))
-cfg = MPCConfig.for_robot("ghost", horizon=10, **over)
-state, cmd, t_off, slabs = bench.make_input_ring(cfg, B, 0, device, 50, 0.1)
-ctl = BatchedMPCController(B, cfg, device=device, extra_outputs=True)
-ctl.reset_at(-t_off); ctl.update_controller_params(torch.from_numpy(cmd.T.copy()).to(device))
-recs = []
-for k in range(60):
-    ctl.get_action(0.01 * k, slabs[k % 50]); torch.cuda.synchronize()
-    if k >= 40:
-        g = ctl.extra["grf"].cpu().numpy().reshape(B, 12).astype(np.float64)
-        it, nc = ctl._handle.last_iterations(B, ctl._stream())
-        recs.append(np.column_stack([g[:, :6], it, nc]))
-np.save("gpurun_out/stamp4.npy", np.array(recs))
-r = np.array(recs)
-for k in range(3):
-    t0, t1 = r[k, :, 0], r[k, :, 1]
-    base = t0.min(); t0 = (t0 - base) % (1 << 24); t1 = (t1 - base) % (1 << 24)
-    print(f"tick {k}: kernel span {t1.max() * 0.01:.1f} us; first-round starts p50 {np.percentile(t0, 25) * 0.01:.1f}; last start {t0.max() * 0.01:.1f}; mean dur {np.mean(t1 - t0) * 0.01:.1f} us; sum dur/2048 {np.sum(t1 - t0) * 0.01 / 2048:.1f}")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RG_MPC_LIB"] = os.path.join(ROOT, "robot_gym_amd", "csrc", "librg_mpc_stamp.so")
+sys.path.insert(0, ROOT)
+import numpy as np   # noqa: E402
+import torch   # noqa: E402
+import bench   # noqa: E402
+from robot_gym_amd.core.config import MPCConfig   # noqa: E402
+from robot_gym_amd.controllers.mpc.batched import BatchedMPCController   # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+overs = [json.loads(a) for a in sys.argv[2:]] or [{}]
+torch.cuda.set_device(0)
+device = torch.device("cuda", 0)
+for over in overs:
+    fixed = over.pop("fixed_cmd", None)
+    cfg = MPCConfig.for_robot("ghost", horizon=10, **over)
+    state, cmd, t_off, slabs = bench.make_input_ring(cfg, B, 0, device, 50, 0.1, (0.3, 0.0, 0.0) if fixed else None)
+    ctl = BatchedMPCController(B, cfg, device=device, extra_outputs=True)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()).to(device))
+    recs = []
+    for k in range(60):
+        ctl.get_action(0.01 * k, slabs[k % 50])
+        torch.cuda.synchronize()
+        if k >= 40:
+            g = ctl.extra["grf"].cpu().numpy().reshape(B, 12).astype(np.float64)
+            it, nc = ctl._handle.last_iterations(B, ctl._stream())
+            recs.append(np.column_stack([g[:, :2], it, nc]))
+    r = np.array(recs)
+    print(f"== {over} fixed_cmd={bool(fixed)} batch {B}")
+    spans = []
+    for k in range(r.shape[0]):
+        t0, t1 = r[k, :, 0], r[k, :, 1]
+        base = t0.min()
+        t0, t1 = (t0 - base) % (1 << 24), (t1 - base) % (1 << 24)
+        spans.append((t1.max() * 0.01, np.sum(t1 - t0) * 0.01 / 2048, np.percentile(t0, 99) * 0.01))
+    sp = np.array(spans)
+    print(f"kernel span {sp[:, 0].mean():.1f} us (max {sp[:, 0].max():.1f}); mean slot load {sp[:, 1].mean():.1f} us; p99 job start {sp[:, 2].mean():.1f} us")
+    dur = ((r[:, :, 1] - r[:, :, 0]) % (1 << 24)) * 0.01
+    start = r[:, :, 0]
+    for nc in (1, 2, 3, 4):
+        m = r[:, :, 3] == nc
+        if not m.any():
+            continue
+        d, it = dur[m], r[:, :, 2][m]
+        line = f"  nc={nc}: n/tick {m.sum() / r.shape[0]:.0f} dur mean {d.mean():.1f} p50 {np.median(d):.1f} p90 {np.percentile(d, 90):.1f} p99 {np.percentile(d, 99):.1f} max {d.max():.1f} | iters mean {it.mean():.1f} max {it.max():.0f}"
+        if len(d) > 100:   # duration against solver work
+            A = np.column_stack([np.ones(len(it)), it])
+            coef = np.linalg.lstsq(A, d, rcond=None)[0]
+            line += f" | dur ~ {coef[0]:.1f} + {coef[1]:.2f} * iters"
+        print(line)
+        for lo, hi in ((0, 0), (1, 2), (3, 5), (6, 10), (11, 20), (21, 40), (41, 80), (81, 1000)):
+            mm = (it >= lo) & (it <= hi)
+            if mm.sum() >= 3:
+                print(f"      iters {lo:3d}..{hi:4d}: n {mm.sum():6d}  dur mean {d[mm].mean():6.1f} max {d[mm].max():6.1f}")
+    ctl.close()

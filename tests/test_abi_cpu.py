@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     lib = mpc_abi.load_library()
-    assert lib.rg_mpc_abi_version() == mpc_abi.ABI_VERSION == 3
+    assert lib.rg_mpc_abi_version() == mpc_abi.ABI_VERSION == 4
     assert lib.rg_mpc_config_size() == C.sizeof(mpc_abi.CConfig)
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     bodies = {name: body for body, name in re.findall(r"typedef struct \{([^{}]*)\} (\w+);", src)}

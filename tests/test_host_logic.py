@@ -145,13 +145,16 @@ def test_vec_env_host_logic_keeps_each_envs_own_step(monkeypatch):
     from robot_gym_amd.gym import vec_env
     from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
     from tests.fake_envs import FakeGoEnv, SplitGoEnv, FakeRobotGymEnv, Box
+    from robot_gym_amd.gym.split_step import one_pass
     monkeypatch.setattr(vec_env, "BatchedMPCController", _RecordingBatchedController)
     monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
     cfg = MPCConfig.for_robot("ghost")          # VY_OFFSET 0.08, WZ_OFFSET -0.025
     B = 5
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=3)
-    envs = [FakeGoEnv(cfg, state, 0, BatchSlotController), FakeGoEnv(cfg, state, 1, BatchSlotController, on_target=True),
-            SplitGoEnv(cfg, state, 2, BatchSlotController, follow_camera=True), FakeGoEnv(cfg, state, 3, BatchSlotController, follow_camera=True),
+    OnePassGoEnv = one_pass(FakeGoEnv, FakeRobotGymEnv)   # generic interceptor after the task env in the MRO: no env code restated
+    assert [k.__name__ for k in OnePassGoEnv.__mro__[:4]] == ["OnePassFakeGoEnv", "FakeGoEnv", "_InterceptFakeRobotGymEnv", "FakeRobotGymEnv"]
+    envs = [FakeGoEnv(cfg, state, 0, BatchSlotController), OnePassGoEnv(cfg, state, 1, BatchSlotController, on_target=True),
+            SplitGoEnv(cfg, state, 2, BatchSlotController, follow_camera=True), OnePassGoEnv(cfg, state, 3, BatchSlotController, follow_camera=True),
             SplitGoEnv(cfg, state, 4, BatchSlotController)]
     venv = vec_env.MPCVecEnv(envs, config=cfg)
     assert len(venv) == B and venv[3] is envs[3] and venv.action_space == Box([-1, -1], [1, 1]) and venv.observation_space is envs[0].observation_space
@@ -171,7 +174,7 @@ def test_vec_env_host_logic_keeps_each_envs_own_step(monkeypatch):
         row = env.simulation.applied[-1]
         assert row[0] == b and np.array_equal(row[1:4], want[b])               # every env applied ITS row
         assert env.simulation.robot.equipment_updates == (1 if b in (2, 3) else 0)
-        assert env.pre_controller_runs == (1 if isinstance(env, SplitGoEnv) else 2)   # capture + replay vs pre_step once
+        assert env.pre_controller_runs == (2 if type(env) is FakeGoEnv else 1)   # capture + replay vs one pass (pre_step / post_step, or the interceptor)
     np.testing.assert_array_equal(ctl.calls[0]["t_robot"].numpy(), np.zeros(B))
     np.testing.assert_array_equal(ctl.calls[0]["rpy"].numpy(), state["rpy"])
     for k in range(3):
@@ -257,12 +260,12 @@ def test_vec_env_worker_processes_match_the_in_process_path(monkeypatch):
 
 def test_vec_env_refuses_a_non_repeatable_step_before_anything_is_applied(monkeypatch):
     """An env without pre_step / post_step is stepped twice per tick (capture + replay).  If its pre-controller code derives a
-    different command on the second pass, the slot controller refuses INSIDE get_action -- before ApplyStepAction -- and the
-    split-step mixin is the documented fix (one pass)."""
+    different command on the second pass, the slot controller refuses INSIDE get_action -- before ApplyStepAction -- the wrapper
+    is unusable from then on (the batched controller has already advanced), and split_step.one_pass is the documented fix."""
     import torch
     from robot_gym_amd.core.config import MPCConfig
     from robot_gym_amd.gym import vec_env
-    from robot_gym_amd.gym.split_step import RobotGymEnvSplitStep
+    from robot_gym_amd.gym.split_step import one_pass
     from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
     from tests.fake_envs import FakeRobotGymEnv
     monkeypatch.setattr(vec_env, "BatchedMPCController", _RecordingBatchedController)
@@ -280,14 +283,19 @@ def test_vec_env_refuses_a_non_repeatable_step_before_anything_is_applied(monkey
     with pytest.raises(RuntimeError, match="not repeatable"):
         venv.step(np.zeros((2, 3), dtype=np.float32))
     assert all(len(e.simulation.applied) == 0 for e in envs)       # nothing reached ApplyStepAction
+    with pytest.raises(RuntimeError, match="unusable: an earlier step\\(\\) failed half-way"):   # the batched call had been made: fatal for the batch
+        venv.step(np.zeros((2, 3), dtype=np.float32))
 
-    class Fixed(RobotGymEnvSplitStep, Drifting):                   # the mixin's halves of RobotGymEnv.step: one pass per tick
-        @property
-        def _simulation(self): return self.simulation
+    Fixed = one_pass(Drifting, FakeRobotGymEnv)                    # Drifting.step's own code runs once per tick
     envs = [Fixed(cfg, state, b, BatchSlotController) for b in range(2)]
     venv = vec_env.MPCVecEnv(envs, config=cfg)
-    obs, rew, done, info = venv.step(np.zeros((2, 3), dtype=np.float32))
-    assert obs.shape == (2, 2) and all(len(e.simulation.applied) == 1 and getattr(e, "calls", 0) == 0 for e in envs)
+    for k in range(1, 3):
+        obs, rew, done, info = venv.step(np.zeros((2, 3), dtype=np.float32))
+        assert obs.shape == (2, 2) and all(len(e.simulation.applied) == k and e.calls == k for e in envs)
+        assert all(abs(float(e.simulation.applied[-1][1]) - 0.01 * k) < 1e-7 for e in envs)   # the command of THAT single pass
+    # alone, outside MPCVecEnv, the interceptor is a pass-through
+    with pytest.raises(RuntimeError, match="outside MPCVecEnv.step"):
+        envs[0].step((0.0, 0.0, 0.0))
 
 
 def test_vec_env_matches_reference_batch_env_behaviour(monkeypatch):
@@ -402,6 +410,57 @@ def test_reference_env_step_fixture_and_fake_env_fidelity(monkeypatch):
         assert [e.simulation.applied[-1][:4].round(6).tolist() for e in envs] == tick["applied_row_head"]
         assert [e.simulation.robot.equipment_updates for e in envs] == tick["equipment_updates"]
     assert calls == gv["batched_calls"]
+    # (3) the REAL GoEnv stepped in one pass (split_step.one_pass(GoEnv, RobotGymEnv), recorded by make_golden.py): the interceptor
+    # sits after GoEnv in the MRO, GoEnv.step's own pre-controller code (show_plot on, counting _update_plot) ran ONCE per tick,
+    # and the transitions, applied rows and batched calls are those of the two-pass path
+    g1 = gold["vec_env_one_pass"]
+    assert g1["mro"] == ["OnePassGoEnv", "GoEnv", "_InterceptRobotGymEnv", "RobotGymEnv"]
+    assert g1["batched_calls"] == gv["batched_calls"]
+    for k, (t1, t2) in enumerate(zip(g1["ticks"], gv["ticks"])):
+        assert t1["update_plot_calls"] == [k + 1] * 3
+        assert all(t1[f] == t2[f] for f in ("obs", "reward", "done", "applied_row_head", "equipment_updates"))
+    # ... and the fake one-pass env reproduces it
+    from robot_gym_amd.gym.split_step import one_pass
+    from tests.fake_envs import FakeRobotGymEnv
+    OnePass = one_pass(FakeGoEnv, FakeRobotGymEnv)
+    del calls[:]
+    envs = [OnePass(cfg, state, 0, BatchSlotController, config=cfg), OnePass(cfg, state, 1, BatchSlotController, config=cfg, on_target=True),
+            OnePass(cfg, state, 2, BatchSlotController, config=cfg, follow_camera=True)]
+    venv = vec_env.MPCVecEnv(envs, config=cfg)
+    for tick in g1["ticks"]:
+        o, r, d, i = venv.step(actions)
+        assert np.asarray(o).tolist() == tick["obs"] and [e.simulation.applied[-1][:4].round(6).tolist() for e in envs] == tick["applied_row_head"]
+        assert [e.simulation.robot.equipment_updates for e in envs] == tick["equipment_updates"]
+    assert calls == g1["batched_calls"]
+
+
+def test_ui_glue_of_the_controller_plugins():
+    """setup_ui_params / read_ui_params (reference controllers/mpc/mpc_controller.py:68-81: three sliders Vx, Vy, Wz in [-2, 2]
+    starting at 0, read back in that order; called as statics by gym/envs/go_to/go_env.py:113,136-139 and
+    playground/playground.py:47,95) and get_standing_action (:111-113) on both plugin classes, with a recording stub client.
+    The expected calls are those the reference's own class made when make_golden.py imported it (tests/golden/adapter.json)."""
+    import json
+    from robot_gym_amd.controllers.mpc.mpc_controller import MPCController
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "adapter.json")))["ui_glue"]
+
+    class Client:
+        def __init__(self): self.log, self.values = [], {}
+        def addUserDebugParameter(self, name, lo, hi, start):
+            self.log.append(["addUserDebugParameter", name, lo, hi, start])
+            self.values[len(self.values) + 10] = 0.25 * (len(self.values) + 1)
+            return len(self.values) + 9
+        def readUserDebugParameter(self, handle):
+            self.log.append(["readUserDebugParameter", handle])
+            return self.values[handle]
+
+    for cls in (MPCController, BatchSlotController):
+        c = Client()
+        ui = cls.setup_ui_params(c)          # called on the CLASS, before any instance exists (go_env.py:113)
+        vals = cls.read_ui_params(c, ui)
+        assert list(ui) == gold["ui_handles"] and list(vals) == gold["ui_values"], cls.__name__
+        assert c.log == gold["client_log"], cls.__name__
+        assert list(cls.get_standing_action()) == gold["standing_action"]
 
 
 def test_fake_simulation_clock_is_the_reference_clock():
