@@ -34,7 +34,7 @@ BATCH_PER_GPU = 4096
 HORIZON = 10
 EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the timed region
 RING = 50          # state slabs in the input ring = ticks of one 0.5 s trot cycle (measured contacts stay gait-consistent)
-PROFILE_TAG = "r3"
+PROFILE_TAG = "r4"
 # algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off)
 ALGO_BYTES_PER_STEP = 1110
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -108,7 +108,7 @@ def source_hash():
 
 
 def profile_tag(workload_key):
-    """profiles/<tag>_* file prefix of a workload: r2 for the headline, r2_<key> for the others (tools/collect_profiles.sh)."""
+    """profiles/<tag>_* file prefix of a workload: PROFILE_TAG for the headline, PROFILE_TAG_<key> for the others (tools/collect_profiles.sh)."""
     return PROFILE_TAG if workload_key == "headline" else f"{PROFILE_TAG}_{workload_key}"
 
 
@@ -263,7 +263,7 @@ def self_launch(args, argv):
     import socket
     import subprocess
     if not args.dry_launch:
-        have = torch.cuda.device_count()   # counts devices without initialising the GPU
+        have = torch.cuda.device_count()   # this process makes no other GPU call; the ranks are a fresh child process either way
         if have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {have} GPU(s)")
     with socket.socket() as sk:
@@ -273,6 +273,12 @@ def self_launch(args, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--force-launcher"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    # RCCL: no algorithm / protocol knob is forced.  The one exchange is the optional all-gather of 0.98 MB per rank; RCCL's
+    # all-gather is a ring (7 serial hops, each bound by one xGMI link), and the alternative -- every rank sends its slab
+    # straight to its 7 peers over the pairwise links -- is chosen at the torch level (core/sharding.py, schedule "direct":
+    # one grouped batch of point-to-point operations), not by an environment variable.  Both are timed below whenever there
+    # is more than one rank.  NCCL_DEBUG=WARN only makes a failing rendezvous say why.
+    env.setdefault("NCCL_DEBUG", "WARN")
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for l in res.stdout.splitlines():
@@ -322,7 +328,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="robots per GPU")
-    ap.add_argument("--allgather", action="store_true", help="`value` includes the RCCL all-gather of the action slab inside the timed step (default: a second timed pass reports it as config.with_allgather_steps_per_s)")
+    ap.add_argument("--total-batch", type=int, default=None, help="robots over ALL ranks, sharded with core.sharding.shard_bounds (shards may differ by one robot); overrides --batch")
+    ap.add_argument("--allgather", action="store_true", help="`value` includes the RCCL all-gather of the action slab inside the timed step (default: further timed passes report it as config.with_allgather_steps_per_s / with_allgather_direct_steps_per_s)")
+    ap.add_argument("--allgather-schedule", choices=("ring", "direct"), default="ring", help="schedule of the all-gather that --allgather puts into `value` (core/sharding.py)")
     ap.add_argument("--dry-launch", action="store_true", help="CPU dry run of the multi-rank protocol: gloo, a stub controller, no GPU")
     ap.add_argument("--force-launcher", action="store_true", help="start the ranks through self_launch even for --gpus 1 (tests the launcher on a 1-GPU box)")
     ap.add_argument("--kin-mode", type=int, default=0, help="1 = foot positions / Jacobians from joint angles on the device (chain kinematics replacing controllers/mpc/kinematics.py)")
@@ -331,7 +339,7 @@ def main():
     ap.add_argument("--audit-k", type=int, default=None, help="audit lane picks per tick (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--admm-iters", type=int, default=None, help="fixed ADMM iteration count (disables the convergence test)")
-    ap.add_argument("--solver", type=int, default=None, help="0 = ADMM, 1 = exact active set")
+    ap.add_argument("--solver", type=int, default=None, help="0 = ADMM only, 1 = exact active set for every robot, 2 = ADMM with the exact re-solve behind it, 3 = hybrid (default): exact for one / two stance legs, ADMM for three / four")
     ap.add_argument("--cold-start", action="store_true", help="start ADMM from scratch every tick (default: warm start from the robot's previous-tick iterate)")
     ap.add_argument("--cap", type=int, default=None, help="ADMM iteration cap (keeps the convergence test)")
     ap.add_argument("--rho", type=float, default=None)
@@ -415,15 +423,22 @@ def main():
         over["audit_k"] = args.audit_k
     cfg = MPCConfig.for_robot(args.robot, horizon=args.horizon, **over)
     B = args.batch
+    total_robots = world * B
+    if args.total_batch is not None:   # uneven shards: rank r owns shard_bounds(total, r, world)
+        from robot_gym_amd.core.sharding import shard_bounds
+        lo_, hi_ = shard_bounds(args.total_batch, rank, world)
+        B, total_robots = hi_ - lo_, args.total_batch
     fixed_cmd = (0.3, 0.0, 0.0) if args.fixed_cmd else None
     # the robot batch shards trivially: rank r owns robots [r*B, (r+1)*B) -- different seed per shard
     gait = synthetic.random_gaits(B, cfg, seed=rank) if args.random_schedule else None
     state, cmd, t_off, slabs = make_input_ring(cfg, B, rank, device, ring, args.jitter, fixed_cmd, gait, args.random_schedule, args.chain_geometry)
-    gathered = torch.empty(world * B, 60, dtype=torch.float32, device=device) if dist is not None else None
+    gathered = torch.empty(total_robots, 60, dtype=torch.float32, device=device) if dist is not None else None
 
-    def run(slab_list, steps, warmup, events, cfg_run=None, allgather=False):
+    def run(slab_list, steps, warmup, events, cfg_run=None, allgather=None):
         """`warmup` untimed then `steps` timed ticks on a fresh controller; returns (seconds, handle-side profile, stats).
-        allgather: every step also all-gathers the [B, 60] action slab over the process group (RCCL over xGMI)."""
+        allgather: "ring" / "direct" -- every step also all-gathers the [B, 60] action slab over the process group (RCCL over
+        xGMI) with that schedule (core/sharding.py)."""
+        from robot_gym_amd.core.sharding import all_gather_actions
         ctl = DryController(B) if dry else BatchedMPCController(B, cfg_run or cfg, device=device, extra_outputs=False)
         if gait is not None:
             ctl.set_gait(**gait)
@@ -434,7 +449,7 @@ def main():
         def one_step(k):
             act = ctl.get_action(0.01 * k, slab_list[k % nslab])
             if allgather:
-                dist.all_gather_into_tensor(gathered, act)
+                all_gather_actions(act, out=gathered, schedule=allgather, total=(args.total_batch if args.total_batch is not None else None))
 
         for k in range(warmup):
             one_step(k)
@@ -468,15 +483,24 @@ def main():
         return float(tt.item())
 
     use_ag = bool(args.allgather and dist is not None)
-    elapsed, (nprof, kms, robots), stats, wn, ctl = run(slabs, args.steps, args.warmup, not args.no_kernel_events, allgather=use_ag)
+    elapsed, (nprof, kms, robots), stats, wn, ctl = run(slabs, args.steps, args.warmup, not args.no_kernel_events, allgather=(args.allgather_schedule if use_ag else None))
     elapsed = max_over_ranks(elapsed)
-    # SURVEY.md 8e asks for both rates: the other one (with the all-gather when `value` is without it, and vice versa) from a
-    # second timed pass of the same steps -- only when there is a process group to gather over
-    other_elapsed = None
+    # SURVEY.md 8e asks for both rates -- without the all-gather and with it -- and the exchange has two schedules (ring /
+    # direct, core/sharding.py): further timed passes of the same steps, only when there is a process group to gather over
+    ag_elapsed = {}
+    plain_elapsed = None if use_ag else elapsed
     if dist is not None:
-        ctl.close()
-        other_elapsed, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, allgather=not use_ag)
-        other_elapsed = max_over_ranks(other_elapsed)
+        for schedule in ("ring", "direct"):
+            if use_ag and schedule == args.allgather_schedule:
+                ag_elapsed[schedule] = elapsed
+                continue
+            ctl.close()
+            e_, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, allgather=schedule)
+            ag_elapsed[schedule] = max_over_ranks(e_)
+        if use_ag:
+            ctl.close()
+            e_, _, _, _, ctl = run(slabs, args.steps, args.warmup, False)
+            plain_elapsed = max_over_ranks(e_)
     # per-rank kernel times (ms): every rank reports its own hipEvent averages
     per_rank_kms = None
     if dist is not None:
@@ -490,7 +514,7 @@ def main():
     #    prediction from the previous tick is then perfect)
     #  - PCIe-inclusive rate: the gym side holds the robot state on the host -- pinned buffers, one upload of all inputs
     #    and one download of the action slab per tick
-    pcie_value = static_value = cold_value = None
+    pcie_value = static_value = cold_value = steady_value = None
     if world == 1 and dist is None and not args.no_extras and not dry:
         from robot_gym_amd.controllers.mpc.batched import PackedState
         names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
@@ -520,9 +544,14 @@ def main():
             ctl.close()
             el_c, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, dataclasses.replace(cfg, warm_start=0))
             cold_value = B * args.steps / el_c
+        # the driver's default line times the first ticks after a cold start with per-kernel events on every 4th tick; the
+        # steady state -- warm starts and cost-class predictions settled, no events -- over 200 ticks:
+        ctl.close()
+        el_ss, _, _, _, ctl = run(slabs, 200, 20, False)
+        steady_value = B * 200 / el_ss
 
     if rank == 0:
-        total_units = world * B * args.steps
+        total_units = total_robots * args.steps
         value = total_units / elapsed
         names = wn[:5]
         if "fused" in wn[1] or "sched" in wn[1]:   # one QP launch over all stance-leg counts, then the exact re-solve launches
@@ -563,14 +592,21 @@ def main():
                        "input_schedule": ("one frozen state slab (static inputs)" if ring == 1 else
                                           f"ring of {ring} state slabs resident in HBM, one per tick: v_world / rpy_rate scaled by 1 +- {args.jitter}, roll/pitch +- {0.2 * args.jitter:.3g} rad, foot positions +- {20 * args.jitter:.3g} %, measured contacts following the gait"),
                        "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value, "cold_start_steps_per_s": cold_value,
-                       "robot": cfg.robot, "solver": f"admm rho={cfg.admm_rho} relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""), "admm_iterations": stats,
+                       "steady_state_steps_per_s": steady_value,
+                       "robot": cfg.robot,
+                       "solver": {0: "ADMM only", 1: "exact active set for every robot", 2: "ADMM + exact re-solve", 3: "hybrid: exact active set (1-2 stance legs), ADMM + exact re-solve (3-4)"}[cfg.solver]
+                                 + f"; admm rho={cfg.admm_rho} (x{cfg.admm_rho34_scale} wrench body) relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""),
+                       "admm_iterations": stats,
                        "warm_start": warm_on, "kin_mode": cfg.kin_mode, "allgather": use_ag,
-                       "with_allgather_steps_per_s": (None if other_elapsed is None else (total_units / (elapsed if use_ag else other_elapsed))),
-                       "without_allgather_steps_per_s": (total_units / elapsed if other_elapsed is None else total_units / (other_elapsed if use_ag else elapsed)),
+                       "with_allgather_steps_per_s": (total_units / ag_elapsed["ring"] if "ring" in ag_elapsed else None),
+                       "with_allgather_direct_steps_per_s": (total_units / ag_elapsed["direct"] if "direct" in ag_elapsed else None),
+                       "allgather_schedule": (args.allgather_schedule if use_ag else None),
+                       "without_allgather_steps_per_s": total_units / plain_elapsed,
                        "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                        "kernel_ms_per_rank": per_rank_kms, "dry_launch": dry,
                        "audit": audit,
-                       "pcie_inclusive_steps_per_s": pcie_value, "sharding": f"{world} x {B} robots, no data-path collective",
+                       "pcie_inclusive_steps_per_s": pcie_value,
+                       "sharding": (f"{world} x {B} robots" if args.total_batch is None else f"{total_robots} robots over {world} ranks (shard_bounds: {total_robots // world} or {total_robots // world + 1} each)") + ", no data-path collective",
                        "kernel_sources": source_hash()},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(prof, names[dom]),

@@ -262,7 +262,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
   d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->rho34_scale = c->admm_rho34_scale; d->admm_switch = c->admm_switch; d->admm_extrap = c->admm_extrap > 0.0 ? c->admm_extrap : INFINITY;
-  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = c->solver; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
+  d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = (c->solver == RG_SOLVER_ADMM) ? RG_SOLVER_ADMM : RG_SOLVER_AUTO /* device side: do the ADMM bodies hand unconverged robots to the exact re-solve lists */; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)
     for (int b = 0; b < H; b++) {
@@ -290,7 +290,7 @@ extern "C" {
 
 int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
-const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_resolve_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
+const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_resolve_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,rg_swing_ik_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
 
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
@@ -332,7 +332,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   AL(h->st.reset_time, B); AL(h->st.flags, B); AL(h->st.last_desired, B);
   AL(h->st.ring, 3 * W * B); AL(h->st.ring_len, B); AL(h->st.ring_head, B);
   AL(h->st.fsum, 3 * B); AL(h->st.fcorr, 3 * B);
-  AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B);
+  AL(h->st.latched, 12 * B); AL(h->st.swing_q, 12 * B); AL(h->st.swing_valid, B); AL(h->st.ik_in, 24 * B); AL(h->st.ik_flag, 4 * B);
   AL(h->st.cmd, 3 * B); AL(h->st.rec, B * RG_REC_N);
   if (cfg->warm_start) { AL(h->st.warm_z, B * RG_WARM_N); AL(h->st.warm_y, B * RG_WARM_N); }
   if (cfg->warm_start && h->exact12) { AL(h->st.ws_ids, B * RG_WS_MAX); AL(h->st.ws_cnt, B); }
@@ -508,6 +508,9 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (h->fused) {
     if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
     else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->dcfg, h->st, dout, B, h->cu_count, s));
+  } else {   // no QP launch to carry the swing IK lanes: a launch of their own
+    hipLaunchKernelGGL(rg_swing_ik_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, dout, B);
+    HIPCHK(h, hipGetLastError());
   }
   if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
   if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));

@@ -79,6 +79,8 @@ struct DevState {
   double *latched;      // [12][B]
   double *swing_q;      // [12][B]
   int *swing_valid;     // [B] 12-bit mask
+  double *ik_in;        // [6][4B] front kernel -> swing IK lanes: the swing foot's target (base frame) and the leg's current joint angles
+  int *ik_flag;         // [4B] bit 0: this (robot, leg) swings this tick (its target needs the IK)
   float *cmd;           // [3][B] rg_mpc_set_command copy
   double *rec;          // [B][RG_REC_N]
   float *warm_z, *warm_y;   // [B][RG_WARM_N] previous-tick ADMM iterate (warm start); float32: it is only a starting point

@@ -15,7 +15,7 @@ SWING_Q_ABS_TOL = 1e-5  # float32 action cast of float64 IK results
 def _check(gpu, orc):
     for k, (og, oo) in enumerate(zip(gpu, orc)):
         m = helpers.compare_tick(og, oo)
-        assert m["tau_rel_elem_max"] <= 10 * TORQUE_REL_TOL, (k, m)   # per joint, |dtau_j| / max(|tau_j|, 1 N m)
+        assert m["tau_rel_elem_max"] <= TORQUE_REL_TOL, (k, m)   # per JOINT, |dtau_j| / max(|tau_j|, 1 N m): the strict reading of the bar (default admm_tol 1e-7)
         assert m["leg_state_mismatch"] == 0 and m["desired_mismatch"] == 0, (k, m)
         assert m["phase_bits"] == 0, (k, m)
         assert m["gains"] == 0.0, (k, m)
@@ -110,7 +110,7 @@ def test_contact_lookahead_extension(oracle_lib, horizon):
     _check(gpu, orc)
 
 
-@pytest.mark.parametrize("solver", [1, 2])   # 1 = exact active set, 2 = ADMM with exact retry (default)
+@pytest.mark.parametrize("solver", [1, 2, 3])   # 1 = exact active set, 2 = ADMM with exact retry, 3 = hybrid (default: these two-leg robots on the exact body)
 @pytest.mark.parametrize("gait", ["pace", "bound"])
 def test_statically_unbalanced_gaits(oracle_lib, gait, solver):
     """Lateral (pace) and fore/hind (bound) leg pairs cannot balance the body: many constraints are active
@@ -128,25 +128,55 @@ def test_statically_unbalanced_gaits(oracle_lib, gait, solver):
         assert stats["retried_exact"] > 0   # the fallback is what makes these cases pass
 
 
-def test_exact_solver_on_standard_trot(oracle_lib):
-    cfg = MPCConfig.for_robot("ghost", solver=1)
+@pytest.mark.parametrize("poison", [True, False])   # with and without NaN bits left in every CU's LDS before each tick
+@pytest.mark.parametrize("warm", [1, 0])
+def test_exact_solver_on_standard_trot(oracle_lib, warm, poison):
+    """RG_SOLVER_ACTIVE_SET: every robot on an exact body inside the QP launch (force space for two legs, wrench space for
+    four), warm-started from the previous working set or cold: float32 output rounding is all that separates it from the
+    oracle's exact solver, and nobody needs the re-solve launch."""
+    cfg = MPCConfig.for_robot("ghost", solver=1, warm_start=warm)
     state, cmd, t_off = synthetic.make_states(256, cfg, seed=13)
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=6, jitter=0.1)
-    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=6, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=6, jitter=0.1, poison=poison)
     for g, o in zip(gpu, orc):
         m = helpers.compare_tick(g, o)
         assert m["tau_rel_max"] <= 1e-6 and m["grf_rel_max"] <= 1e-6 and m["leg_state_mismatch"] == 0, m   # float32 output rounding only
+        assert g["solver_stats"]["failures"] == 0 and g["solver_stats"]["retried_exact"] == 0, g["solver_stats"]
+    assert gpu[-1]["bins"][2] > 0 and gpu[-1]["bins"][4] > 0
+
+
+def test_hybrid_default_solves_trot_robots_exactly(oracle_lib):
+    """The default plan (RG_SOLVER_HYBRID): two-leg robots come out of the QP launch with the oracle's exact solution (float32
+    rounding), four-leg robots within the ADMM tolerance; the stored working set makes the following ticks cheaper (applications
+    of G per robot, what st.iters reports for the exact body) and changes no result."""
+    B = 512
+    cfg = MPCConfig.for_robot("ghost")
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=17)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=10, jitter=0.05)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=10, jitter=0.05)
+    cold = helpers.run_gpu(MPCConfig.for_robot("ghost", warm_start=0), state, cmd, t_off, ticks=10, jitter=0.05)
+    _check(gpu, orc)
+    _check(cold, orc)
+    for k, (g, cg, o) in enumerate(zip(gpu, cold, orc)):
+        two = g["stance_legs"] == 2
+        a_g, a_c, a_o = (x["action"].reshape(B, 12, 5)[:, :, 4].astype(np.float64) for x in (g, cg, o))
+        scale = np.maximum(np.abs(a_o).max(1), 1.0)
+        assert two.sum() > 0 and (np.abs(a_g - a_o).max(1) / scale)[two].max() <= 1e-6, k
+        assert (np.abs(a_c - a_o).max(1) / scale)[two].max() <= 1e-6, k
+        assert g["solver_stats"]["failures"] == 0 and g["solver_stats"]["retried_exact"] == 0, g["solver_stats"]
+    two = gpu[-1]["stance_legs"] == 2
+    assert gpu[-1]["iters"][two].mean() <= cold[-1]["iters"][two].mean(), (gpu[-1]["iters"][two].mean(), cold[-1]["iters"][two].mean())
 
 
 def test_warm_start_stays_within_tolerance(oracle_lib):
     """Warm start (the default): ADMM starts from the previous tick's iterate when the contact set is unchanged.
     Same tolerance as the cold solve; fewer iterations on slowly changing states."""
-    cfg = MPCConfig.for_robot("ghost", warm_start=1)
+    cfg = MPCConfig.for_robot("ghost", warm_start=1, solver=2)   # an ADMM property: every robot on an ADMM body
     state, cmd, t_off = synthetic.make_states(192, cfg, seed=15)
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=30, jitter=0.05)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=30, jitter=0.05)
     _check(gpu, orc)
-    cold = helpers.run_gpu(MPCConfig.for_robot("ghost", warm_start=0), state, cmd, t_off, ticks=30, jitter=0.05)
+    cold = helpers.run_gpu(MPCConfig.for_robot("ghost", warm_start=0, solver=2), state, cmd, t_off, ticks=30, jitter=0.05)
     _check(cold, orc)
     it_warm = np.mean([g["solver_stats"]["iters_mean"] for g in gpu[5:]])
     it_cold = np.mean([g["solver_stats"]["iters_mean"] for g in cold[5:]])
@@ -230,7 +260,8 @@ def test_steady_state_filter_full_batch_1024(oracle_lib):
     _check(gpu, orc)
     last = gpu[-1]
     assert last["solver_stats"]["failures"] == 0 and last["bins"][2] > 0 and last["bins"][4] > 0
-    assert last["solver_stats"]["iters_mean"] > 25   # steady-state QPs are the hard ones (about 64 from a cold start, 40 with the warm start)
+    four = last["stance_legs"] == 4   # (ADMM robots; the two-leg robots' iteration count is their exact body's applications of G)
+    assert last["iters"][four].mean() > 25   # steady-state QPs are the hard ones
 
 
 def test_gait_phase_bit_exact_after_an_hour(oracle_lib):
@@ -501,20 +532,24 @@ def _audit_run(cfg, B, ticks, seed=0, jitter=0.1):
     return acts, ctl
 
 
-@pytest.mark.parametrize("horizon,B,ticks", [(10, 4096, 30), (20, 1024, 10)])
-def test_audit_lane_re_solves_converged_robots_and_finds_nothing(horizon, B, ticks):
+@pytest.mark.parametrize("horizon,B,ticks,solver", [(10, 4096, 30, 2), (10, 4096, 30, 3), (20, 1024, 10, 3)])
+def test_audit_lane_re_solves_converged_robots_and_finds_nothing(horizon, B, ticks, solver):
     """Always-on audit: ~audit_k converged ADMM solves per tick go through the exact active-set bodies on the side stream;
     with the library defaults nothing may come back over 1e-4, no exact solve may fail, and the count must be about
-    audit_k x AUDIT_PERIOD per audited tick (Poisson picks on the first tick and then on ticks 4, 12, 20 ...)."""
+    audit_k x AUDIT_PERIOD per audited tick (Poisson picks on the first tick and then on ticks 4, 12, 20 ...) -- times the share
+    of the robots that run an ADMM body: under the default hybrid plan (horizon 10) the one- and two-leg robots are solved
+    exactly and there is nothing of theirs to audit."""
     from robot_gym_amd.core.mpc_abi import AUDIT_PERIOD
-    cfg = MPCConfig.for_robot("ghost", horizon=horizon)
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon, solver=solver)
     acts, ctl = _audit_run(cfg, B, ticks)
     a = ctl.audit_stats()
+    bins = ctl.bin_counts()
     ctl.close()
     helpers.assert_audit_clean(a)
     launches = sum(1 for t in range(ticks) if t == 0 or t % AUDIT_PERIOD == AUDIT_PERIOD // 2)
-    expect = cfg.audit_k * AUDIT_PERIOD * launches
-    assert 0.7 * expect <= a["audited"] + a["audit_dropped"] <= 1.3 * expect, (a, expect)
+    admm_share = (bins[3] + bins[4]) / B if (solver == 3 and horizon == 10) else 1.0
+    expect = cfg.audit_k * AUDIT_PERIOD * launches * admm_share
+    assert 0.6 * expect <= a["audited"] + a["audit_dropped"] <= 1.4 * expect, (a, expect)
     assert 0.0 < a["audit_max_rel"] <= 1e-4 and a["audit_max_rel_elem"] <= 1e-3, a
     print("audit", horizon, a)
 
@@ -531,7 +566,7 @@ def test_audit_lane_notices_a_sloppy_exit_and_never_touches_outputs():
     assert a0["audited"] == 0
     for x, y in zip(acts_on, acts_off):
         assert np.array_equal(x, y)
-    sloppy = MPCConfig.for_robot("ghost", admm_tol=1e-3, admm_extrap=0.0, admm_accel=0, audit_k=16)
+    sloppy = MPCConfig.for_robot("ghost", admm_tol=1e-3, admm_extrap=0.0, admm_accel=0, audit_k=16, solver=2)   # every robot on an ADMM body
     _, ctl = _audit_run(sloppy, 2048, 9)
     a = ctl.audit_stats()
     ctl.close()
@@ -539,13 +574,15 @@ def test_audit_lane_notices_a_sloppy_exit_and_never_touches_outputs():
     print("sloppy exit seen by the audit:", a)
 
 
-def test_strict_per_joint_reading_is_met_at_admm_tol_1e_7(oracle_lib):
-    """north_star: "torques within 1e-4 rel of the CPU reference".  The library default (admm_tol 1e-6) meets it per robot --
-    max_j |dtau_j| / max(max_j |tau_j|, 1 N m) -- with 3-5x margin; read per joint, |dtau_j| / max(|tau_j|, 1 N m), a small joint
-    torque next to a large one carries the large one's absolute error and the default reaches 3e-4.  profiles/
-    r3_tolerance_table.md has the curve; this pins its strict end: admm_tol = 1e-7 (6.5 % slower on the headline bench) keeps
-    every JOINT within 1e-4 as well."""
-    cfg = MPCConfig.for_robot("ghost", admm_tol=1e-7)
+@pytest.mark.parametrize("solver", [2, 3])
+def test_strict_per_joint_reading_is_met_by_the_default_tolerance(oracle_lib, solver):
+    """north_star: "torques within 1e-4 rel of the CPU reference".  Read per robot -- max_j |dtau_j| / max(max_j |tau_j|, 1 N m) --
+    admm_tol 1e-6 meets it with 3-5x margin; read per JOINT, |dtau_j| / max(|tau_j|, 1 N m), a small joint torque next to a large
+    one carries the large one's absolute error and 1e-6 reaches 3e-4 (profiles/r3_tolerance_table.md has the curve).  The
+    default is its strict end, admm_tol = 1e-7: every joint within 1e-4, for the ADMM bodies alone (solver 2) and under the
+    default hybrid plan."""
+    cfg = MPCConfig.for_robot("ghost", solver=solver)
+    assert cfg.admm_tol == 1e-7
     state, cmd, t_off = synthetic.make_states(1024, cfg, seed=0)
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=8, jitter=0.1)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=8, jitter=0.1, poison=False)
@@ -564,7 +601,7 @@ def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
     lists run in their own launch next to the ADMM launch."""
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
     import torch
-    cfg = MPCConfig.for_robot("ghost", duty_factor=(0.55,) * 4, init_phase=(0.0, 0.5, 0.0, 0.5), init_state=(1, 1, 1, 1))
+    cfg = MPCConfig.for_robot("ghost", duty_factor=(0.55,) * 4, init_phase=(0.0, 0.5, 0.0, 0.5), init_state=(1, 1, 1, 1), solver=2)   # (under the hybrid plan the exact body solves these two-leg robots in the QP launch)
     B, ticks = 96, 20
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=3)
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=ticks, jitter=0.1)
@@ -593,18 +630,30 @@ def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
     assert sum(direct[1:]) >= 0.5 * sum(retried[1:]) > 0, (direct, retried)   # from then on most exact solves are of robots that skipped ADMM ...
     assert sum(capped[1:]) <= 0.5 * sum(retried[1:]), (capped, retried)   # ... only robots whose contact set just changed, or on their 16th-tick ADMM probe, run to the cap
     assert launches >= sum(1 for r in retried[:-1] if r > 0) - 2, (launches, retried)   # a tick after exact solves gives the direct lists their own launch
+    # a reset robot is a fresh robot: no direct routing from before the reset, ADMM first (round-3 advisor finding)
+    assert direct[-1] > 0
+    ctl.reset_at(-t_off)
+    st = helpers.perturb(state, ticks, 0.1)
+    dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+    dev["contact"] = torch.from_numpy(synthetic.gait_consistent_contacts(cfg, 0.01 * ticks + t_off, state["_flip"])).cuda()
+    ctl.get_action(0.01 * ticks, dev)
+    torch.cuda.synchronize()
+    n_after, _ = ctl._handle.last_direct_count(ctl._stream())
+    assert n_after == 0 and ctl.solver_stats()["retried_exact"] >= 1, (n_after, ctl.solver_stats())
     ctl.close()
 
 
 @pytest.mark.parametrize("seed", [71 + 7 * i for i in range(int(os.environ.get("RG_GUARD_SEEDS", "1")))])
+@pytest.mark.parametrize("poison", [True, False])   # with and without NaN bits left in every CU's LDS before each tick
 @pytest.mark.parametrize("horizon", [10, 20])
-def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon, seed):
-    """Guard for the exact re-solve launch (rg_qp_fused_retry_kernel / rg_qp_sched_retry_kernel: all exact bodies of a horizon
-    inlined behind one work loop, the kernel whose code generation DESIGN.md section 9 records as fragile): ADMM is cut off after
-    8 iterations, so EVERY robot with a stance leg is handed to it; per-robot duty factors from 0.3 to 0.9, half of the robots
-    trotting and half walking, put one-, two-, three- and four-leg robots into the same launch, and 1024 robots on 128 workgroups make every workgroup run several bodies
-    one after the other.  Exact solves: agreement with the oracle to float32 output rounding, no breakdowns."""
-    cfg = MPCConfig.for_robot("ghost", horizon=horizon, admm_iters=8)
+def test_every_robot_through_the_exact_resolve_kernel(oracle_lib, horizon, seed, poison):
+    """Guard for the exact re-solve launch (rg_qp_resolve_kernel / rg_qp_sched_retry_kernel: ONE exact body per kernel that
+    handles every stance-leg count -- round 3 inlined one body per count behind the work loop, the kernel whose code generation
+    depended on source arrangement): ADMM (solver 2: every robot on an ADMM body) is cut off after 8 iterations, so EVERY robot
+    with a stance leg is handed to it; per-robot duty factors from 0.3 to 0.9, half of the robots trotting and half walking,
+    put one-, two-, three- and four-leg robots into the same launch, and 1024 robots on 128 workgroups make every workgroup
+    solve several robots one after the other.  Exact solves: agreement with the oracle to float32 output rounding, no breakdowns."""
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon, admm_iters=8, solver=2)
     B = 1024
     state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed)
     gait = synthetic.random_gaits(B, cfg, seed=seed, duty_range=(0.3, 0.9))
@@ -613,7 +662,7 @@ def test_every_robot_through_the_multi_body_exact_kernel(oracle_lib, horizon, se
     gait["init_phase"] = gait["init_phase"].copy()
     gait["init_phase"][:, ::2] = np.array([0.0, 0.5, 0.25, 0.75])[:, None]
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait)
-    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=3, jitter=0.1, gait=gait, poison=poison)
     _check(gpu, orc)
     for k, g in enumerate(gpu):
         bins, stats = g["bins"], g["solver_stats"]

@@ -31,6 +31,12 @@ def _gather_worker(rank, world, port, tmp):
     full = torch.arange(64 * 60, dtype=torch.float32).view(64, 60)
     out = all_gather_actions(full[lo:hi].clone())
     ok = torch.equal(out, full)
+    # the direct schedule (every rank sends its slab straight to every peer: one hop over the pairwise xGMI links) and uneven
+    # shards (61 robots over the ranks: slabs that differ by one row travel padded)
+    ok = ok and torch.equal(all_gather_actions(full[lo:hi].clone(), schedule="direct"), full)
+    for schedule in ("ring", "direct"):
+        l2, h2 = shard_bounds(61, rank, world)
+        ok = ok and torch.equal(all_gather_actions(full[l2:h2].clone(), schedule=schedule, total=61), full[:61])
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -67,9 +73,34 @@ def test_bench_launches_its_own_ranks_dry_run_world_size_2():
     assert c["dry_launch"] is True and c["rccl_ranks"] == 2 and c["backend"] == "gloo" and len(c["kernel_ms_per_rank"]) == 2
     assert c["with_allgather_steps_per_s"] > 0 and c["without_allgather_steps_per_s"] == out["value"]
     assert c["sharding"].startswith("2 x 64 robots")
+    assert c["with_allgather_direct_steps_per_s"] > 0 and c["allgather_schedule"] is None
     # a rank count the node cannot serve is refused before anything is launched
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
     assert res.returncode != 0 and "GPU(s)" in res.stderr
+
+
+def test_bench_dry_run_world_size_8_uneven_shards():
+    """The shape of the driver's scaling run at N = 8 (SCALE record: n_gpus, eight ranks in the process group, both all-gather
+    rates -- ring and direct -- next to the rate without, one row of kernel times per rank), on CPU over gloo, and with a batch
+    that does not divide by the ranks: 8 x 4096 + 5 robots through core.sharding.shard_bounds (shards of 4096 and 4097)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-launch", "--total-batch", str(8 * 64 + 5), "--steps", "2",
+                          "--warmup", "1", "--ring", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    c = out["config"]
+    assert out["n_gpus"] == 8 and c["rccl_ranks"] == 8 and len(c["kernel_ms_per_rank"]) == 8 and all(len(r) == 6 for r in c["kernel_ms_per_rank"])
+    assert out["scaling"] == "weak" and out["value"] == c["without_allgather_steps_per_s"] > 0
+    assert c["with_allgather_steps_per_s"] > 0 and c["with_allgather_direct_steps_per_s"] > 0
+    assert c["sharding"].startswith("517 robots over 8 ranks")
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 517) < 1e-6 * 517        # value = all robots of all ranks per step time
 
 
 def test_synthetic_states_are_deterministic_and_shaped():
