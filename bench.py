@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--check", type=int, default=None, help="convergence vote period")
     ap.add_argument("--accel", type=int, default=None, help="first iteration at which a vote may extrapolate the iterate (admm_accel; 0 = off)")
     ap.add_argument("--rho34", type=float, default=None, help="admm_rho34_scale: first-stage rho of the wrench-space ADMM body = rho x this")
+    ap.add_argument("--rho-sched", type=float, default=None, help="admm_rho_sched_scale: first-stage rho of the schedule body = rho x this")
     ap.add_argument("--rho2", type=float, default=None, help="second-stage ADMM rho of the contact-schedule body (0 = single stage)")
     ap.add_argument("--switch", type=int, default=None, help="first-stage iteration count of the contact-schedule body")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region (roofline.kernel_ms is then empty)")
@@ -413,6 +414,8 @@ def main():
         over["admm_rho2"] = args.rho2
     if args.rho34 is not None:
         over["admm_rho34_scale"] = args.rho34
+    if args.rho_sched is not None:
+        over["admm_rho_sched_scale"] = args.rho_sched
     if args.switch is not None:
         over["admm_switch"] = args.switch
     if args.lookahead:

@@ -149,6 +149,8 @@ typedef struct {
                                Its iteration count falls with rho at every percentile (admm_rho x 0.5: mean 54 -> ~43), where the
                                force-space body's tail grows; with the exact body taking the one- and two-leg robots
                                (RG_SOLVER_HYBRID) these robots are the launch's longest jobs */
+  double admm_rho_sched_scale; /* the same for the schedule body (any contact schedule; three and four legs at horizon 20), which
+                               iterates in wrench space too */
 } rg_mpc_config;
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per

@@ -80,6 +80,7 @@ class MPCConfig:
     reserved3: int = 0           # must be 0
     audit_tol: float = 1e-4      # per-robot torque error the audit counts as over tolerance
     admm_rho34_scale: float = 0.5   # first-stage rho of the wrench-space ADMM body (three / four legs, horizon 10) = admm_rho x this: its iteration count falls with rho at every percentile (1.0: mean 54, 0.5: 43; measured 0.3 ... 1.0, profiles/r4_rho34.txt)
+    admm_rho_sched_scale: float = 1.0   # the same for the schedule body (contact schedules; three / four legs at horizon 20)
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

@@ -38,7 +38,7 @@ class CConfig(C.Structure):
         ("admm_tol", d), ("admm_check", i32), ("contact_lookahead", i32), ("warm_start", i32), ("reserved2", i32),
         ("admm_rho2", d), ("admm_switch", i32), ("admm_accel", i32), ("admm_extrap", d),
         ("accel_cos2", d), ("accel_rmax", d), ("accel_rmin", d), ("accel_rate_cap", d),
-        ("audit_k", i32), ("reserved3", i32), ("audit_tol", d), ("admm_rho34_scale", d),
+        ("audit_k", i32), ("reserved3", i32), ("audit_tol", d), ("admm_rho34_scale", d), ("admm_rho_sched_scale", d),
     ]
 
 

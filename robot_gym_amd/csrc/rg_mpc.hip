@@ -216,7 +216,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
   if (!(c->accel_cos2 > 0 && c->accel_cos2 < 1) || !(c->accel_rmin > 0 && c->accel_rmin < c->accel_rmax && c->accel_rmax < 1) || !(c->accel_rate_cap > 0 && c->accel_rate_cap < 1)) { err = "extrapolation thresholds out of range: 0 < accel_cos2 < 1, 0 < accel_rmin < accel_rmax < 1, 0 < accel_rate_cap < 1"; return RG_MPC_ERR_INVALID; }
   if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / (2 * RG_AUDIT_PERIOD) || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
-  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0 || !(c->admm_rho34_scale > 0 && c->admm_rho34_scale <= 10)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
+  if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0 || !(c->admm_rho34_scale > 0 && c->admm_rho34_scale <= 10) || !(c->admm_rho_sched_scale > 0 && c->admm_rho_sched_scale <= 10)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
@@ -261,7 +261,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   for (int i = 0; i < 12; i++) d->tip[i] = c->toe_xyz[i] + c->toe_com[i];
   memcpy(d->base_com, c->base_com, sizeof(d->base_com));
   d->ik_damping = c->ik_damping; d->ik_max_step = c->ik_max_step;
-  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->rho34_scale = c->admm_rho34_scale; d->admm_switch = c->admm_switch; d->admm_extrap = c->admm_extrap > 0.0 ? c->admm_extrap : INFINITY;
+  d->rho = c->admm_rho; d->relax = c->admm_relax; d->rho2 = c->admm_rho2; d->rho34_scale = c->admm_rho34_scale; d->rho_sched_scale = c->admm_rho_sched_scale; d->admm_switch = c->admm_switch; d->admm_extrap = c->admm_extrap > 0.0 ? c->admm_extrap : INFINITY;
   d->admm_abs_tol = c->admm_tol * c->mass * c->gravity; d->admm_prim_tol = 10.0 * d->admm_abs_tol; d->admm_check = c->admm_check; d->lookahead = c->contact_lookahead ? 1 : 0; d->solver = (c->solver == RG_SOLVER_ADMM) ? RG_SOLVER_ADMM : RG_SOLVER_AUTO /* device side: do the ADMM bodies hand unconverged robots to the exact re-solve lists */; d->warm = (c->warm_start && !c->contact_lookahead) ? 1 : 0;
   const int H = c->horizon;
   for (int a = 0; a < H; a++)

@@ -60,6 +60,7 @@ struct DevCfg {
   int plan, admm_switch; // plan 1: the front kernel sorts robots into cost classes for the fused QP launch (RG_COST_*); admm_switch: first-stage iterations
   double rho2;           // second-stage ADMM rho (0 = single stage)
   double rho34_scale;    // first-stage rho of the wrench-space ADMM body (three / four legs, horizon 10) = rho x this
+  double rho_sched_scale; // ... of the schedule body (contact schedules; three / four legs at horizon 20)
   double accel_k[4];     // thresholds of the extrapolation test {accel_cos2 0.9, accel_rmax 0.98, accel_rmin 0.5, accel_rate_cap 0.999}
                          // (rg_mpc_config): read from here (scalar loads) because as literals they were materialised in VGPR pairs at
                          // kernel entry and spilled to scratch by every workgroup

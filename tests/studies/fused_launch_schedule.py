@@ -61,4 +61,14 @@ for over in overs:
             mm = (it >= lo) & (it <= hi)
             if mm.sum() >= 3:
                 print(f"      iters {lo:3d}..{hi:4d}: n {mm.sum():6d}  dur mean {d[mm].mean():6.1f} max {d[mm].max():6.1f}")
+    # who ends the launch: the latest-finishing jobs of the last ticks (start, duration, stance legs, solver work now and in the
+    # tick before -- what the front kernel predicted the cost class from)
+    for k in range(r.shape[0] - 3, r.shape[0]):
+        t0, t1 = r[k, :, 0], r[k, :, 1]
+        base = t0.min()
+        t0, t1 = ((t0 - base) % (1 << 24)) * 0.01, ((t1 - base) % (1 << 24)) * 0.01
+        order = np.argsort(-t1)[:8]
+        print(f"  tick {k}: span {t1.max():.1f}; last finishers: " + "; ".join(f"nc{int(r[k, b, 3])} start {t0[b]:.0f} dur {t1[b] - t0[b]:.0f} it {int(r[k, b, 2])} (prev {int(r[k - 1, b, 2])}, prev nc{int(r[k - 1, b, 3])})" for b in order))
+        busy = np.array([((t0 <= t) & (t1 > t)).sum() for t in np.arange(0, t1.max(), 10.0)])
+        print("      jobs in flight every 10 us:", busy.tolist())
     ctl.close()
