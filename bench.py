@@ -35,8 +35,11 @@ HORIZON = 10
 EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the timed region
 RING = 50          # state slabs in the input ring = ticks of one 0.5 s trot cycle (measured contacts stay gait-consistent)
 PROFILE_TAG = "r4"
-# algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off)
-ALGO_BYTES_PER_STEP = 1110
+# algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off): inputs 320, persistent
+# controller state read + written ~550, the swing-IK hand-over (flags 32, target + start angles of ~1.5 swinging legs ~150),
+# action row 240
+ALGO_BYTES_PER_STEP = 1290
+EXACT_WS_BYTES = 80         # exact body: the robot's stored working set (64 one-byte ids + count) read, the new one written
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 F64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz (v_fma_f64 issues at 4 cycles per wave)
 
@@ -253,6 +256,31 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
     finally:
         O.set_qp_mode(0)
     return out
+
+
+def dropin_latency(cfg, calls=300):
+    """End-to-end latency of the drop-in plugin class, `MPCController.get_action()` at batch 1 (BASELINE configs[0]; the
+    reference's bar is the playground's 10 ms control tick, playground/playground.py:122-126): the state gather through the
+    reference's Robot getter names (a stub robot serving a synthetic state: PyBullet's own getter time is NOT in this number),
+    four Jacobian callbacks, one pinned host-to-device copy, the tick's three launches, the action row back and the stream
+    synchronisation."""
+    from robot_gym_amd import synthetic
+    from robot_gym_amd.controllers.mpc.mpc_controller import MPCController
+    from tests.fake_envs import StubRobot
+    state, cmd, _ = synthetic.make_states(1, cfg, seed=0)
+    clock = [0.0]
+    ctl = MPCController(StubRobot(cfg, state, 0), lambda: clock[0], config=cfg)
+    ctl.update_controller_params((0.3, 0.0, 0.0))
+    lat = []
+    for k in range(calls + 20):
+        clock[0] = 0.01 * k
+        t0 = time.perf_counter()
+        ctl.get_action()
+        lat.append(time.perf_counter() - t0)
+    ctl._batched.close()
+    lat = np.array(lat[20:]) * 1e6
+    return {"mean": round(float(lat.mean()), 1), "p50": round(float(np.median(lat)), 1), "p99": round(float(np.percentile(lat, 99)), 1),
+            "calls": calls, "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet), includes H2D, 3 launches, D2H, sync"}
 
 
 def self_launch(args, argv):
@@ -517,7 +545,7 @@ def main():
     #    prediction from the previous tick is then perfect)
     #  - PCIe-inclusive rate: the gym side holds the robot state on the host -- pinned buffers, one upload of all inputs
     #    and one download of the action slab per tick
-    pcie_value = static_value = cold_value = steady_value = None
+    pcie_value = static_value = cold_value = steady_value = dropin_us = None
     if world == 1 and dist is None and not args.no_extras and not dry:
         from robot_gym_amd.controllers.mpc.batched import PackedState
         names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
@@ -552,6 +580,11 @@ def main():
         ctl.close()
         el_ss, _, _, _, ctl = run(slabs, 200, 20, False)
         steady_value = B * 200 / el_ss
+        if B == 1:
+            try:
+                dropin_us = dropin_latency(cfg)
+            except Exception as e:   # a reported extra
+                dropin_us = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         total_units = total_robots * args.steps
@@ -566,7 +599,9 @@ def main():
         # algorithmic bytes of the dominant launch: the per-step I/O of DESIGN.md section 5, plus -- with the warm start -- the
         # previous-tick ADMM iterate (z, y as float32, read and written: 16 B per QP variable, 3 * legs * horizon variables)
         warm_on = bool(cfg.warm_start) and not args.lookahead
-        algo_bytes_launch = ALGO_BYTES_PER_STEP * units[dom] + (16 * 3 * args.horizon * sum(nc * robots[nc] for nc in range(1, 5)) if (warm_on and dom == 1) else 0)
+        exact_upto = (4 if cfg.solver == 1 else 2 if cfg.solver == 3 else 0) if (args.horizon == 10 and not args.lookahead) else 0   # stance-leg counts on an exact body
+        warm_bytes = sum((EXACT_WS_BYTES if nc <= exact_upto else 16 * 3 * args.horizon * nc) * robots[nc] for nc in range(1, 5))
+        algo_bytes_launch = ALGO_BYTES_PER_STEP * units[dom] + (warm_bytes if (warm_on and dom == 1) else 0)
         achieved = (algo_bytes_launch / dur_s) / 1e9 if dur_s > 0 else 0.0
         if args.random_schedule:
             wl, wkey = f"batch={B} quadrupeds per GPU, horizon={args.horizon}, per-robot duty U(0.5,0.8), randomised contact schedule with 10% drop-outs re-drawn per tick (BASELINE configs[4])", "config5"
@@ -595,7 +630,7 @@ def main():
                        "input_schedule": ("one frozen state slab (static inputs)" if ring == 1 else
                                           f"ring of {ring} state slabs resident in HBM, one per tick: v_world / rpy_rate scaled by 1 +- {args.jitter}, roll/pitch +- {0.2 * args.jitter:.3g} rad, foot positions +- {20 * args.jitter:.3g} %, measured contacts following the gait"),
                        "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value, "cold_start_steps_per_s": cold_value,
-                       "steady_state_steps_per_s": steady_value,
+                       "steady_state_steps_per_s": steady_value, "dropin_get_action_latency_us": dropin_us,
                        "robot": cfg.robot,
                        "solver": {0: "ADMM only", 1: "exact active set for every robot", 2: "ADMM + exact re-solve", 3: "hybrid: exact active set (1-2 stance legs), ADMM + exact re-solve (3-4)"}[cfg.solver]
                                  + f"; admm rho={cfg.admm_rho} (x{cfg.admm_rho34_scale} wrench body) relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""),

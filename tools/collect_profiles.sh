@@ -4,7 +4,7 @@
 #   stats: only the --kernel-trace --stats pass (and the bench line);  full (default): + HBM / SQ / f64 counter passes.
 # Summarise with tools/summarize_profiles.py <tag>.  The program after `--` is python3 itself (no env/bash hop).
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 MODE=${2:-full}
 shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

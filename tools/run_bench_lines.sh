@@ -2,6 +2,7 @@
 # Runs on the GPU box (via gpurun) AFTER profiles/ holds the summaries of the current kernel sources: the bench line of every
 # BASELINE workload, now carrying the profile-derived fields (roofline.traffic, roofline.issue_view).  -> gpurun_out/bench_<key>.json
 set -u
+TAG=${TAG:-r4}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 run() { local key=$1; shift; python3 bench.py --steps 20 --warmup 5 "$@" > gpurun_out/bench_$key.json 2> gpurun_out/bench_$key.err; echo "$key: $(python3 -c "import json;d=json.loads(open('gpurun_out/bench_$key.json').read());print(round(d['value']/1e6,3),'M steps/s', d['roofline']['kernel_ms'], 'traffic', d['roofline']['traffic'])")"; }
@@ -15,6 +16,6 @@ run b32768 --batch 32768
 run kin1 --kin-mode 1
 # the geometry kin_mode 1 computes on the device (chain forward kinematics of the synthetic joint angles) handed to kin_mode 0
 # as inputs: the same QPs as the kin1 line, so the difference between the two is the cost of the on-device kinematics
-tools/collect_profiles.sh r3_kin0chain stats --chain-geometry > gpurun_out/collect_kin0chain.log 2>&1
+tools/collect_profiles.sh ${TAG}_kin0chain stats --chain-geometry > gpurun_out/collect_kin0chain.log 2>&1
 run kin0chain --chain-geometry
-python3 tools/vec_env_bench.py 20 > gpurun_out/r3_vec_env_host.txt 2> gpurun_out/r3_vec_env_host.err; cat gpurun_out/r3_vec_env_host.txt
+python3 tools/vec_env_bench.py 20 > gpurun_out/${TAG}_vec_env_host.txt 2> gpurun_out/${TAG}_vec_env_host.err; cat gpurun_out/${TAG}_vec_env_host.txt

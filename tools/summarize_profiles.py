@@ -9,7 +9,7 @@ so the raw value is reported and the 2x-corrected value is given as an upper bou
 import collections, csv, glob, json, os, shutil, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"       # r3 (headline) or r3_<workload key>: bench.py profile_tag()
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"       # r4 (headline) or r4_<workload key>: bench.py profile_tag()
 workload_key = tag.split("_", 1)[1] if "_" in tag else "headline"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
@@ -17,8 +17,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("rg_front_kernel", "rg_qp_fused_retry_kernel", "rg_qp_fused_kernel", "rg_qp_sched_retry_kernel", "rg_qp_sched_kernel", "rg_qp_admm_tile_kernel<1", "rg_qp_admm_tile_kernel<2",
-              "rg_qp_admm_tile_kernel<3", "rg_qp_admm_tile_kernel<4", "rg_reset_kernel", "rg_hybrid"):
+    for k in ("rg_front_kernel", "rg_qp_resolve_kernel", "rg_qp_fused_kernel", "rg_qp_sched_retry_kernel", "rg_qp_sched_kernel", "rg_swing_ik_kernel", "rg_reset_kernel", "rg_hybrid"):
         if k in name:
             return name[name.index(k):].split("(")[0]
     return None
