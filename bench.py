@@ -202,15 +202,19 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
             ob.states[b].reset_time = -float(t_off[b])
         return ob
 
-    # the port allocates per step; on many-core hosts fewer threads can be faster -> pick the best count first
+    # per-thread workspaces (no heap calls in the loop over robots); still, a container's CPU quota or the memory system can make
+    # fewer threads faster than all logical CPUs -> measure a few counts first and report the search (`thread_search`, `host`)
     best_threads, best_rate = cores, 0.0
+    search = {}
     if Bs >= 64:
-        for nthreads in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8)}, reverse=True):
+        for nthreads in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
             ob = fresh(nthreads)
             ob.step(0.0, inputs[0])
             t0 = time.perf_counter()
             ob.step(0.01, inputs[1 % len(inputs)])
-            rate = Bs / (time.perf_counter() - t0)
+            ob.step(0.02, inputs[2 % len(inputs)])
+            rate = 2 * Bs / (time.perf_counter() - t0)
+            search[str(nthreads)] = round(rate)
             if rate > best_rate:
                 best_threads, best_rate = nthreads, rate
     else:
@@ -226,7 +230,19 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
         el = time.perf_counter() - t0
         if el > budget_s or ticks >= 2000:
             break
-    out = {"value": Bs * ticks / el, "unit": "controller steps/s", "cores": cores, "kind": "port",
+    def host_cpus():
+        """What the box really gives this process: logical CPUs, the affinity mask, and the cgroup CPU quota (a container can
+        see 256 logical CPUs and be allowed 32 CPU-seconds per second: more threads than that only add contention)."""
+        info = {"cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None, "cgroup_cpu_max": None}
+        for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            try:
+                info["cgroup_cpu_max"] = open(path).read().strip()
+                break
+            except OSError:
+                pass
+        return info
+
+    out = {"value": Bs * ticks / el, "unit": "controller steps/s", "cores": cores, "kind": "port", "host": host_cpus(), "thread_search": search,
            "sample": f"{Bs} robots x {ticks} ticks of this workload (seed 0, same per-tick input variation), float64 C oracle with exact active-set QP, OpenMP over robots"}
 
     def timed(nthreads, budget):
@@ -520,14 +536,14 @@ def main():
     # direct, core/sharding.py): further timed passes of the same steps, only when there is a process group to gather over
     ag_elapsed = {}
     plain_elapsed = None if use_ag else elapsed
+    ag_note = None
     if dist is not None:
-        for schedule in ("ring", "direct"):
-            if use_ag and schedule == args.allgather_schedule:
-                ag_elapsed[schedule] = elapsed
-                continue
+        if use_ag:
+            ag_elapsed[args.allgather_schedule] = elapsed
+        if "ring" not in ag_elapsed:
             ctl.close()
-            e_, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, allgather=schedule)
-            ag_elapsed[schedule] = max_over_ranks(e_)
+            e_, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, allgather="ring")
+            ag_elapsed["ring"] = max_over_ranks(e_)
         if use_ag:
             ctl.close()
             e_, _, _, _, ctl = run(slabs, args.steps, args.warmup, False)
@@ -586,7 +602,7 @@ def main():
             except Exception as e:   # a reported extra
                 dropin_us = {"error": f"{type(e).__name__}: {e}"}
 
-    if rank == 0:
+    def emit_line():
         total_units = total_robots * args.steps
         value = total_units / elapsed
         names = wn[:5]
@@ -638,7 +654,7 @@ def main():
                        "warm_start": warm_on, "kin_mode": cfg.kin_mode, "allgather": use_ag,
                        "with_allgather_steps_per_s": (total_units / ag_elapsed["ring"] if "ring" in ag_elapsed else None),
                        "with_allgather_direct_steps_per_s": (total_units / ag_elapsed["direct"] if "direct" in ag_elapsed else None),
-                       "allgather_schedule": (args.allgather_schedule if use_ag else None),
+                       "allgather_schedule": (args.allgather_schedule if use_ag else None), "allgather_note": ag_note,
                        "without_allgather_steps_per_s": total_units / plain_elapsed,
                        "rccl_ranks": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None),
                        "kernel_ms_per_rank": per_rank_kms, "dry_launch": dry,
@@ -665,6 +681,32 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never the product path
                 out["cpu_baseline"] = {"value": None, "unit": "controller steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
+
+    # The direct (point-to-point) all-gather schedule has only ever run over gloo (no multi-GPU node was reachable): it is timed
+    # LAST and under a watchdog, so that a hang or an error in it cannot cost the run its line -- after the deadline rank 0
+    # prints the line without that number and every rank leaves.
+    if dist is not None and "direct" not in ag_elapsed and os.environ.get("RG_BENCH_DIRECT_ALLGATHER", "1") != "0":
+        import threading
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(float(os.environ.get("RG_BENCH_DIRECT_TIMEOUT_S", "120"))):
+                nonlocal ag_note
+                ag_note = "the direct all-gather pass did not finish within its deadline"
+                if rank == 0:
+                    emit_line()
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            ctl.close()
+            e_, _, _, _, ctl = run(slabs, args.steps, args.warmup, False, allgather="direct")
+            ag_elapsed["direct"] = max_over_ranks(e_)
+        except Exception as e:   # reported, never fatal for the line
+            ag_note = f"direct all-gather pass failed: {type(e).__name__}: {e}"
+        finished.set()
+    if rank == 0:
+        emit_line()
     ctl.close()
     if dist is not None:
         dist.destroy_process_group()
