@@ -347,7 +347,7 @@ class DryController:
         def profile_stride(self, n): pass
         def profile_begin(self, n): self.n = n
         def profile_end(self, stream=None): return 1, [0.001, 0.01, 0.001, 0.0, 0.0, 0.012], [0, 0, 1, 0, 0]
-        def profile_window_names(self): return ["rg_front_kernel", "rg_qp_fused_kernel", "rg_qp_fused_retry_kernel", "-", "-", "step_total"]
+        def profile_window_names(self): return ["rg_front_kernel", "rg_qp_fused_kernel", "rg_qp_resolve_kernel", "-", "-", "step_total"]
 
     def __init__(self, batch):
         self.batch = batch
@@ -635,6 +635,9 @@ def main():
             wkey = "kin0chain" if wkey == "headline" else f"{wkey}_kin0chain"
         if args.random_schedule and args.cap is not None:
             wkey = f"config5_cap{args.cap}"
+        if args.solver is not None and args.solver != MPCConfig.for_robot(args.robot).solver:   # another solver plan than the default: its own profile key
+            wl += f", solver plan {args.solver}"
+            wkey = f"s{args.solver}" if wkey == "headline" else f"{wkey}_s{args.solver}"
         prof = load_profile(B, wkey)
         audit = stats.pop("audit", None)
         out = {

@@ -1,6 +1,6 @@
 """Study (GPU + oracle): torque-error statistics of the default configuration over many robot-ticks, per workload.
-Overrides for experiments: TOL (admm_tol), EXTRAP (admm_extrap), ACCEL (admm_accel); unset = the library defaults.
-Usage: python tests/studies/worst_errors.py [all|h10|h20]"""
+Overrides for experiments: TOL (admm_tol), EXTRAP (admm_extrap), ACCEL (admm_accel), SOLVER (solver plan); unset = the library defaults.
+Usage: python tests/studies/worst_errors.py [all|h10|h20|trot]"""
 import os
 import sys
 
@@ -15,11 +15,13 @@ from robot_gym_amd import synthetic              # noqa: E402
 from tests import helpers                        # noqa: E402
 
 over = {}
-for env, key, conv in (("TOL", "admm_tol", float), ("EXTRAP", "admm_extrap", float), ("ACCEL", "admm_accel", int)):
+for env, key, conv in (("TOL", "admm_tol", float), ("EXTRAP", "admm_extrap", float), ("ACCEL", "admm_accel", int), ("SOLVER", "solver", int)):
     if os.environ.get(env) is not None:
         over[key] = conv(os.environ[env])
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 cases = []
+if which == "trot":
+    cases += [("trot", "ghost", {}, 4096, 50, 0, False)]
 if which in ("all", "h10"):
     cases += [("trot", "ghost", {}, 4096, 50, 0, False), ("trot-k3lso-kin1", "k3lso", dict(kin_mode=1), 2048, 40, 3, False),
               ("walk", "ghost", dict(duty_factor=(0.75,) * 4, init_phase=(0.0, 0.5, 0.25, 0.75), init_state=(1, 1, 1, 1)), 1024, 30, 7, False)]

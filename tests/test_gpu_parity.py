@@ -168,6 +168,34 @@ def test_hybrid_default_solves_trot_robots_exactly(oracle_lib):
     assert gpu[-1]["iters"][two].mean() <= cold[-1]["iters"][two].mean(), (gpu[-1]["iters"][two].mean(), cold[-1]["iters"][two].mean())
 
 
+def test_exact_body_overflow_goes_to_the_resolve_launch(oracle_lib):
+    """Default plan, two-leg robots whose QP has more active constraints than the exact body of the QP launch has room for
+    (40): crouched 15 cm too low, rolled and pitched by half a radian and sliding diagonally at 5 m/s, every other robot has
+    46-50 active rows at the optimum (numpy model of the method, tests/studies/gi_model.py).  Those robots are handed to the exact re-solve launch, whose force-space body holds 64 >= N
+    constraints, come out exact, are marked for direct routing on the following ticks, and nobody fails."""
+    cfg = MPCConfig.for_robot("ghost")
+    B = 64
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=77)
+    fp = state["foot_pos"].reshape(4, 3, B).copy()
+    fp[:, 2, ::2] += 0.15                       # every other robot is 15 cm too low
+    state["foot_pos"] = fp.reshape(12, B).astype(np.float32)
+    vw = state["v_world"].copy()
+    vw[0, ::2] = 5.0                            # ... is much faster than its command
+    vw[1, ::2] = -5.0
+    state["v_world"] = vw
+    rpy = state["rpy"].copy()
+    rpy[0, ::2], rpy[1, ::2] = 0.5, -0.5        # ... and tilted
+    state["rpy"] = rpy
+    state["quat"] = synthetic._quat_from_rpy(rpy[0].astype(np.float64), rpy[1].astype(np.float64), rpy[2].astype(np.float64)).astype(np.float32)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=26, jitter=0.02)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=26, jitter=0.02)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
+    two = gpu[-1]["stance_legs"] == 2
+    assert sum(g["solver_stats"]["retried_exact"] for g in gpu) > 0, [g["solver_stats"]["retried_exact"] for g in gpu]
+    print("exact re-solves per tick:", [g["solver_stats"]["retried_exact"] for g in gpu], "largest two-leg work", gpu[-1]["iters"][two].max())
+
+
 def test_warm_start_stays_within_tolerance(oracle_lib):
     """Warm start (the default): ADMM starts from the previous tick's iterate when the contact set is unchanged.
     Same tolerance as the cold solve; fewer iterations on slowly changing states."""
