@@ -33,7 +33,7 @@ for over in overs:
         if k >= 40:
             g = ctl.extra["grf"].cpu().numpy().reshape(B, 12).astype(np.float64)
             it, nc = ctl._handle.last_iterations(B, ctl._stream())
-            recs.append(np.column_stack([g[:, :2], it, nc]))
+            recs.append(np.column_stack([g[:, :2], it, nc, g[:, 2:8]]))
     r = np.array(recs)
     print(f"== {over} fixed_cmd={bool(fixed)} batch {B}")
     spans = []
@@ -57,6 +57,12 @@ for over in overs:
             coef = np.linalg.lstsq(A, d, rcond=None)[0]
             line += f" | dur ~ {coef[0]:.1f} + {coef[1]:.2f} * iters"
         print(line)
+        # phases of the body (stamp_phase): time from the job's start to the end of each phase
+        ph = ((r[:, :, 4:8] - r[:, :, 0:1]) % (1 << 24))[m] * 0.01
+        ok = (r[:, :, 4:8][m] > 0).all(1)
+        if ok.sum() > 10:
+            e = ph[ok].mean(0)
+            print(f"      phases (mean us): record+tables {e[0]:.1f} | tile build {e[1] - e[0]:.1f} | sweep {e[2] - e[1]:.1f} | solve {e[3] - e[2]:.1f} | outputs {d[ok].mean() - e[3]:.1f}   (n {ok.sum()})")
         for lo, hi in ((0, 0), (1, 2), (3, 5), (6, 10), (11, 20), (21, 40), (41, 80), (81, 1000)):
             mm = (it >= lo) & (it <= hi)
             if mm.sum() >= 3:

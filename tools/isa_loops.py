@@ -17,4 +17,4 @@ for i, l in enumerate(body):
         b = body[labels[m.group(1)]:i]
         c = lambda p: sum(1 for x in b if re.search(p, x))
         print('  loop %-10s len %5d | fma64 %4d mul64 %3d add64 %3d | ds_read %3d ds_write %3d bperm %2d | scratch %3d | barrier %d | rcp/div %2d | waitcnt %3d | readlane %d' % (
-            m.group(1), len(b), c('v_fma_f64'), c('v_mul_f64'), c('v_add_f64'), c('ds_read'), c('ds_write'), c('ds_bpermute|ds_swizzle'), c('scratch_'), c('s_barrier'), c('v_rcp_f64|v_div_'), c('s_waitcnt'), c('v_readlane|v_readfirstlane')))
+            m.group(1), len(b), c('v_fma_f64|v_fmac_f64'), c('v_mul_f64'), c('v_add_f64'), c('ds_read'), c('ds_write'), c('ds_bpermute|ds_swizzle'), c('scratch_'), c('s_barrier'), c('v_rcp_f64|v_div_'), c('s_waitcnt'), c('v_readlane|v_readfirstlane')))
