@@ -31,4 +31,6 @@ lines = [f"{demangle(r['name']):44s} VGPR {r.get('VGPRs'):>3s} AGPR {r.get('AGPR
 out = "\n".join(lines)
 print(out)
 if len(sys.argv) > 1:
-    open(sys.argv[1], "w").write(out + "\n")
+    sys.path.insert(0, ROOT)
+    import bench
+    open(sys.argv[1], "w").write(f"# hipcc -Rpass-analysis=kernel-resource-usage (tools/resource_usage.py), kernel sources {bench.source_hash()}\n" + out + "\n")
