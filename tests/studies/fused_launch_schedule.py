@@ -21,9 +21,16 @@ torch.cuda.set_device(0)
 device = torch.device("cuda", 0)
 for over in overs:
     fixed = over.pop("fixed_cmd", None)
-    cfg = MPCConfig.for_robot("ghost", horizon=10, **over)
-    state, cmd, t_off, slabs = bench.make_input_ring(cfg, B, 0, device, 50, 0.1, (0.3, 0.0, 0.0) if fixed else None)
+    rand = over.pop("random_schedule", None)
+    cfg = MPCConfig.for_robot("ghost", **{"horizon": 10, **over})
+    gait = None
+    if rand:   # BASELINE config 5: per-robot duty factors and a caller-supplied contact schedule
+        from robot_gym_amd import synthetic
+        gait = synthetic.random_gaits(B, cfg, seed=0)
+    state, cmd, t_off, slabs = bench.make_input_ring(cfg, B, 0, device, 50, 0.1, (0.3, 0.0, 0.0) if fixed else None, gait, bool(rand))
     ctl = BatchedMPCController(B, cfg, device=device, extra_outputs=True)
+    if gait is not None:
+        ctl.set_gait(**gait)
     ctl.reset_at(-t_off)
     ctl.update_controller_params(torch.from_numpy(cmd.T.copy()).to(device))
     recs = []
@@ -41,7 +48,7 @@ for over in overs:
         t0, t1 = r[k, :, 0], r[k, :, 1]
         base = t0.min()
         t0, t1 = (t0 - base) % (1 << 24), (t1 - base) % (1 << 24)
-        spans.append((t1.max() * 0.01, np.sum(t1 - t0) * 0.01 / 2048, np.percentile(t0, 99) * 0.01))
+        spans.append((t1.max() * 0.01, np.sum(t1 - t0) * 0.01 / (2048 if cfg.horizon == 10 else 512), np.percentile(t0, 99) * 0.01))
     sp = np.array(spans)
     print(f"kernel span {sp[:, 0].mean():.1f} us (max {sp[:, 0].max():.1f}); mean slot load {sp[:, 1].mean():.1f} us; p99 job start {sp[:, 2].mean():.1f} us")
     dur = ((r[:, :, 1] - r[:, :, 0]) % (1 << 24)) * 0.01
