@@ -74,6 +74,15 @@ for over in overs:
             mm = (it >= lo) & (it <= hi)
             if mm.sum() >= 3:
                 print(f"      iters {lo:3d}..{hi:4d}: n {mm.sum():6d}  dur mean {d[mm].mean():6.1f} max {d[mm].max():6.1f}")
+    # solver work of robots that run their body from a cold start (another stance-leg count than in the tick before: no stored
+    # iterate / working set) against robots continuing on the same body
+    for nc in (2, 4):
+        cur, prev = r[1:, :, 3], r[:-1, :, 3]
+        m_w, m_c = (cur == nc) & (prev == nc), (cur == nc) & (prev != nc)
+        itn, dn = r[1:, :, 2], dur[1:]
+        for name, mm in (("same body as the tick before", m_w), ("body changed (cold start)", m_c)):
+            if mm.sum() > 5:
+                print(f"  nc={nc} {name:32s}: n/tick {mm.sum() / (r.shape[0] - 1):6.0f}  work mean {itn[mm].mean():6.1f} p90 {np.percentile(itn[mm], 90):5.0f} p99 {np.percentile(itn[mm], 99):5.0f} max {itn[mm].max():4.0f} | dur mean {dn[mm].mean():6.1f} p99 {np.percentile(dn[mm], 99):6.1f} max {dn[mm].max():6.1f}")
     # who ends the launch: the latest-finishing jobs of the last ticks (start, duration, stance legs, solver work now and in the
     # tick before -- what the front kernel predicted the cost class from)
     for k in range(r.shape[0] - 3, r.shape[0]):

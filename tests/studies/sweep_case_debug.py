@@ -22,8 +22,17 @@ for k, (g, o) in enumerate(zip(gpu, orc)):
     a_g = g["action"].reshape(B, 12, 5)[:, :, 4].astype(np.float64)
     a_o = o["action"].reshape(B, 12, 5)[:, :, 4].astype(np.float64)
     err = np.abs(a_g - a_o).max(1) / np.maximum(np.abs(a_o).max(1), 1.0)
+    err_j = (np.abs(a_g - a_o) / np.maximum(np.abs(a_o), 1.0)).max(1)   # per joint: the strict reading the tests assert
     qerr = np.abs(g["action"].reshape(B, 12, 5)[:, :, 0].astype(np.float64) - o["action"].reshape(B, 12, 5)[:, :, 0]).max(1)
-    bad = np.where((err > 1e-4) | (qerr > 1e-5))[0]
-    print(f"tick {k}: stats {g['solver_stats']} bins {g['bins']} worst {err.max():.2e} bad robots {len(bad)}")
-    for b in bad[:12]:
-        print(f"    robot {b}: err {err[b]:.2e} q-err {qerr[b]:.1e} stance legs {g['stance_legs'][b]} iters {g['iters'][b]} desired {o['desired'][b]} oracle qp_iters {o['qp_iters'][b]}")
+    bad = np.where((err_j > 1e-4) | (qerr > 1e-5))[0]
+    print(f"tick {k}: stats {g['solver_stats']} bins {g['bins']} worst per robot {err.max():.2e} per joint {err_j.max():.2e} bad robots {len(bad)}")
+    for b in (bad[:12] if len(bad) else np.argsort(-err_j)[:3]):
+        print(f"    robot {b}: err {err[b]:.2e} per joint {err_j[b]:.2e} q-err {qerr[b]:.1e} stance legs {g['stance_legs'][b]} iters {g['iters'][b]} desired {o['desired'][b]} oracle qp_iters {o['qp_iters'][b]}")
+
+# per-leg view of the worst robot of the last tick: forces and body velocity on both sides
+if len(sys.argv) > 3:
+    rb = int(sys.argv[3])
+    for k, (g, o) in enumerate(zip(gpu, orc)):
+        gg, go = g["grf"][rb].astype(np.float64), o["grf"][rb]
+        print(f"tick {k} robot {rb}: v_body gpu {g.get('v_body', np.zeros((B, 3)))[rb]} oracle {o['v_body'][rb]}")
+        print(f"    grf gpu    {np.array2string(gg, precision=5)}\n    grf oracle {np.array2string(go, precision=5)}\n    diff       {np.array2string(gg - go, precision=2)}")
