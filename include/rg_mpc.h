@@ -248,11 +248,12 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);
 
-/* Direct routing (horizon 10, constant contacts, RG_SOLVER_AUTO): a robot whose QP the exact solver had to take over is, while
- * its contact set stays the same, sent straight to the exact solver by the following ticks instead of running ADMM to the
- * iteration cap again (every 16th tick it tries ADMM again); when a recent tick had exact solves, those of the direct robots run
- * in a launch of their own next to the ADMM launch.  direct_robots: robots solved that way in the last step (they are included
- * in rg_mpc_last_solver_stats().retried); concurrent_launches: ticks so far that used the concurrent launch.
+/* Direct routing (horizon 10, constant contacts): a robot whose QP the exact re-solve had to take over -- ADMM at the iteration
+ * cap, an exact body whose working set outgrew its room -- is, while its contact set stays the same, sent straight to the exact
+ * solver with room for it by the following ticks (every 16th tick it tries its first body again).  Under RG_SOLVER_HYBRID /
+ * RG_SOLVER_ACTIVE_SET the first workgroups of the QP launch solve those robots; under RG_SOLVER_AUTO they get a launch of
+ * their own next to the ADMM launch when a recent tick had exact solves.  direct_robots: robots routed that way in the last
+ * step; concurrent_launches: ticks so far that used the separate concurrent launch (0 under the hybrid plan).
  * Synchronises the stream. */
 int rg_mpc_last_direct_count(rg_mpc_handle *h, int32_t *direct_robots, int64_t *concurrent_launches, void *stream);
 

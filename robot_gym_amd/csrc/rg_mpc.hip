@@ -487,7 +487,10 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // host runs ticks ahead of the GPU, so this is a hint, and both paths are correct whatever it says)
   h->st.direct_on = h->direct_on ? 1 : 0;
   h->st.tick = (int)(h->steps & 0x7fffffff);
-  const bool direct_now = h->direct_on && h->fused && *(volatile int *)h->hint_host > 0;
+  // (plans with an exact body in the QP launch: the launch's own head workgroups take the one- and two-leg direct lists,
+  // rg_qp_fused_kernel.inc RG_DIRECT_HEAD -- no side launch, no hint)
+  const bool head = h->direct_on && h->fused && h->exact12 && H == 10 && !h->cfg.contact_lookahead;
+  const bool direct_now = !head && h->direct_on && h->fused && *(volatile int *)h->hint_host > 0;
   h->steps++;
   hipEvent_t *pev = (h->prof_n < h->prof_max && (h->tick++ % h->prof_stride) == 0) ? &h->ev[(size_t)h->prof_n * RG_PROF_EV] : nullptr;
   if (pev) HIPCHK(h, hipEventRecord(pev[0], s));
@@ -515,7 +518,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
   if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));
   if (direct_now) HIPCHK(h, hipStreamWaitEvent(s, h->direct_done, 0));   // the direct robots' actions are part of this tick
-  if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, s, direct_now ? RETRY_LISTS : RETRY_ALL));
+  if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, s, head ? RETRY_AFTER_HEAD : (direct_now ? RETRY_LISTS : RETRY_ALL)));
   else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
   if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
   if (ring >= 0) {

@@ -9,6 +9,7 @@
 
 #define RG_MAXH 20
 #define RG_WARM_N 256 // doubles per robot for the stored ADMM iterate (n <= 240)
+#define RG_EXACT_BIG_WS 32   // stored working sets larger than this run the QP launch's exact body with room for RG_DIRECT_Q constraints (RG_EXACT_Q = 40 is the small body's capacity)
 #define RG_REC_N 96  // doubles per robot in the front->QP record
 // work lists: [0..4] robots per stance-leg count, [5..9] exact re-solve lists, [10..10+RG_COST_CLASSES) cost
 // classes of the fused launch (entry = robot | stance legs << 24), most expensive class first

@@ -661,6 +661,55 @@ def test_strict_per_joint_reading_is_met_by_the_default_tolerance(oracle_lib, so
     assert gpu[-1]["audit"]["audit_max_rel_elem"] <= TORQUE_REL_TOL
 
 
+def test_hybrid_plan_solves_its_direct_lists_inside_the_qp_launch(oracle_lib):
+    """Default plan: two-leg robots whose QP has 46-50 active constraints (the crafted state of
+    test_exact_body_overflow_goes_to_the_resolve_launch) outgrow the QP launch's exact body on the first tick, are re-solved
+    at the end of that tick and marked; from the second tick on the front kernel puts them on the direct list and the QP
+    launch's own head workgroups (RG_DIRECT_HEAD, a body with room for 56 constraints) solve them -- no side launch -- with
+    parity on every tick (LDS poisoned before each)."""
+    from robot_gym_amd.controllers.mpc.batched import BatchedMPCController
+    import torch
+    cfg = MPCConfig.for_robot("ghost")
+    B, ticks = 192, 8
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=77)
+    fp = state["foot_pos"].reshape(4, 3, B).copy()
+    fp[:, 2, ::2] += 0.15
+    state["foot_pos"] = fp.reshape(12, B).astype(np.float32)
+    vw = state["v_world"].copy()
+    vw[0, ::2], vw[1, ::2] = 5.0, -5.0
+    state["v_world"] = vw
+    rpy = state["rpy"].copy()
+    rpy[0, ::2], rpy[1, ::2] = 0.5, -0.5
+    state["rpy"] = rpy
+    state["quat"] = synthetic._quat_from_rpy(rpy[0].astype(np.float64), rpy[1].astype(np.float64), rpy[2].astype(np.float64)).astype(np.float32)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=ticks, jitter=0.02)
+    ctl = BatchedMPCController(B, cfg)
+    ctl.reset_at(-t_off)
+    ctl.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    direct, retried, launches = [], [], 0
+    for k in range(ticks):
+        st = helpers.perturb(state, k, 0.02)
+        dev = {n: torch.from_numpy(np.ascontiguousarray(st[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
+        dev["contact"] = torch.from_numpy(synthetic.gait_consistent_contacts(cfg, 0.01 * k + t_off, state["_flip"])).cuda()
+        ctl._handle.debug_poison_lds(ctl._stream())
+        act = ctl.get_action(0.01 * k, dev)
+        torch.cuda.synchronize()
+        g = {"action": act.cpu().numpy().copy(), **{n: v.cpu().numpy().copy() for n, v in ctl.extra.items()}}
+        _check([g], [orc[k]])
+        stats = ctl.solver_stats()
+        assert stats["failures"] == 0, (k, stats)
+        n, launches = ctl._handle.last_direct_count(ctl._stream())
+        direct.append(n)
+        retried.append(stats["retried_exact"])
+    print("direct-route robots per tick", direct, "exact re-solves after the launch", retried, "side launches", launches)
+    assert direct[0] == 0 and retried[0] >= 8, (direct, retried)      # first tick: the small body overflows, the end-of-tick launch solves
+    assert min(direct[1:]) >= 8, (direct, retried)                    # then those robots are on the direct list (all of it fits the head here) ...
+    assert launches == 0                                              # ... which has no launch of its own
+    # (re-solves after the launch do not stop: a robot whose contact set has just changed, or on its 16th-tick probe, runs the
+    # small body first)
+    ctl.close()
+
+
 def test_persistently_hard_robots_go_straight_to_the_exact_solver(oracle_lib):
     """Direct routing: a robot whose QP the exact solver had to take over is, while its contact set stays the same, sent
     straight to the exact lists by the front kernel of the following ticks (every 16th tick it tries ADMM again) -- it would run
