@@ -48,8 +48,9 @@ typedef enum {
 enum { RG_LEG_SWING = 0, RG_LEG_STANCE = 1, RG_LEG_EARLY_CONTACT = 2, RG_LEG_LOSE_CONTACT = 3 };
 
 /* RG_SOLVER_ADMM: friction-cone ADMM only (iteration cap admm_iters); unconverged robots are counted as failures.
- * RG_SOLVER_ACTIVE_SET: exact dual active-set method only (horizon 10): one / two stance legs in the QP launch, three /
- *   four legs (and every robot of a contact schedule) in the exact re-solve launch.
+ * RG_SOLVER_ACTIVE_SET: exact dual active-set method only (horizon 10), inside the QP launch: the force-space body for one /
+ *   two stance legs, the wrench-space exact body for three / four; the exact re-solve launch takes only a working set that
+ *   outgrew its body or a degenerate stance -- and, under a contact schedule, every robot (that plan has no QP launch).
  * RG_SOLVER_AUTO: ADMM first; robots that have not converged after admm_iters iterations are
  *   re-solved exactly by the active-set kernel (second launch over a retry list).
  * RG_SOLVER_HYBRID (default): what the reference's default solver computes -- the exact minimiser (upstream qpOASES, an

@@ -303,8 +303,9 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   // Launch plans: front -> one QP launch over all stance-leg counts -> exact re-solve launch (normally empty).
   //   RG_SOLVER_HYBRID (horizon 10, constant contacts): exact body for one / two legs, wrench-space ADMM for three / four;
   //     at horizon 20 or with a contact schedule it is RG_SOLVER_AUTO (those QP bodies have no one-wave exact form).
-  //   RG_SOLVER_ACTIVE_SET (horizon 10): the same launch with three / four legs handed to the exact re-solve launch; with
-  //     a contact schedule every robot goes there directly (front kernel plan 0: list = stance-leg bin).
+  //   RG_SOLVER_ACTIVE_SET (horizon 10): the same launch with three / four legs on the wrench-space exact body
+  //     (qp_exact_wrench_robot); the re-solve launch only sees a working set that overflowed or a degenerate stance.  With
+  //     a contact schedule every robot goes to the re-solve launch directly (front kernel plan 0: list = stance-leg bin).
   const bool as_only = cfg->solver == RG_SOLVER_ACTIVE_SET;
   h->exact12 = (cfg->solver == RG_SOLVER_HYBRID || as_only) && cfg->horizon == 10 && !cfg->contact_lookahead;
   h->fused = !(as_only && cfg->contact_lookahead);
@@ -510,7 +511,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // contact schedule has no QP launch of its own: the front kernel's stance-leg bins are the re-solve launch's direct lists)
   if (h->fused) {
     if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
-    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->dcfg, h->st, dout, B, h->cu_count, s));
+    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->dcfg, h->st, dout, B, s));
   } else {   // no QP launch to carry the swing IK lanes: a launch of their own
     hipLaunchKernelGGL(rg_swing_ik_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, dout, B);
     HIPCHK(h, hipGetLastError());
@@ -546,6 +547,7 @@ int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
 }
 
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h) {
+  if (h && !h->fused) return "rg_front_kernel,rg_swing_ik_kernel,rg_qp_resolve_kernel,-,-,step_total";   // the plan without a QP launch
   if (h && h->cfg.contact_lookahead) return h->cfg.horizon == 10 ? "rg_front_kernel,rg_qp_sched_kernel,rg_qp_resolve_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
   return (!h || h->cfg.horizon == 10) ? "rg_front_kernel,rg_qp_fused_kernel,rg_qp_resolve_kernel,-,-,step_total" : "rg_front_kernel,rg_qp_fused_kernel,rg_qp_sched_retry_kernel,-,-,step_total";
 }
