@@ -34,7 +34,7 @@ BATCH_PER_GPU = 4096
 HORIZON = 10
 EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the timed region
 RING = 50          # state slabs in the input ring = ticks of one 0.5 s trot cycle (measured contacts stay gait-consistent)
-PROFILE_TAG = "r4"
+PROFILE_TAG = "r5"
 # algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off): inputs 320, persistent
 # controller state read + written ~550, the swing-IK hand-over (flags 32, target + start angles of ~1.5 swinging legs ~150),
 # action row 240
@@ -98,16 +98,80 @@ def make_input_ring(cfg, B, seed, device, ring, amp, fixed_cmd=None, gait=None, 
     return state, cmd, t_off, slabs
 
 
-def source_hash():
-    """sha256 over the kernel sources and the ABI header: ties committed profiles to the code they were measured on."""
+def compiled_sources(read=None):
+    """Repository-relative paths of the files librg_mpc.so is compiled from: rg_mpc.hip and everything it includes from the
+    repository, transitively (system / HIP headers excluded).  A stray .inc / .h left in csrc/ by an experiment is not part
+    of the library and must not change the hash that ties committed evidence to kernel sources.
+    read(relative path) -> bytes or None: where the file contents come from (default: the working tree)."""
+    import re
+    if read is None:
+        def read(rel):
+            try:
+                return open(os.path.join(ROOT, rel), "rb").read()
+            except OSError:
+                return None
+    seen, todo = {}, ["robot_gym_amd/csrc/rg_mpc.hip"]
+    while todo:
+        rel = os.path.normpath(todo.pop())
+        if rel in seen:
+            continue
+        data = read(rel)
+        if data is None:
+            continue
+        seen[rel] = data
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', data.decode("utf-8", "replace"), flags=re.M):
+            todo.append(os.path.join(os.path.dirname(rel), inc))
+    return dict(sorted(seen.items()))
+
+
+def source_hash(read=None):
+    """sha256 over the compiled kernel sources and the ABI header: ties committed profiles to the code they were measured on.
+    read: see compiled_sources (a test hashes the sources of a COMMIT through `git show <commit>:<path>`)."""
     import hashlib
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "robot_gym_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".inc", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
-    h.update(open(os.path.join(ROOT, "include", "rg_mpc.h"), "rb").read())
+    for rel, data in compiled_sources(read).items():
+        h.update(data)
     return h.hexdigest()[:16]
+
+
+def source_hash_at(commit):
+    """source_hash() of the tree of a commit (needs git and the history: not available on the GPU box)."""
+    import subprocess
+
+    def read(rel):
+        r = subprocess.run(["git", "show", f"{commit}:{rel}"], cwd=ROOT, capture_output=True, timeout=30)
+        return r.stdout if r.returncode == 0 else None
+    return source_hash(read)
+
+
+STAMP_FILE = os.path.join(ROOT, ".rg_source_commit")   # written by tools/stamp_commit.py before a gpurun call (the GPU box has no .git)
+
+
+def git_head():
+    """(commit, dirty) of the compiled sources: from git where there is a history, else from the stamp file
+    tools/stamp_commit.py wrote next to the snapshot -- valid only while its source hash is the tree's."""
+    import subprocess
+    try:
+        head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=20)
+        if head.returncode == 0 and head.stdout.strip():
+            rels = list(compiled_sources())
+            dirty = subprocess.run(["git", "status", "--porcelain", "--"] + rels, cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
+            return head.stdout.strip(), bool(dirty)
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        st = json.load(open(STAMP_FILE))
+        if st.get("source_hash") == source_hash():
+            return st.get("commit"), bool(st.get("dirty"))
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
+def evidence_header():
+    """First line of every evidence file under profiles/: the kernel-source hash and the commit it belongs to."""
+    commit, dirty = git_head()
+    return f"kernel sources {source_hash()} commit {commit or 'unknown'}{' +uncommitted changes' if dirty else ''}"
 
 
 def profile_tag(workload_key):
@@ -210,10 +274,11 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
         for nthreads in sorted({cores, max(1, cores // 2), max(1, cores // 4), max(1, cores // 8), max(1, cores // 16)}, reverse=True):
             ob = fresh(nthreads)
             ob.step(0.0, inputs[0])
-            t0 = time.perf_counter()
-            ob.step(0.01, inputs[1 % len(inputs)])
-            ob.step(0.02, inputs[2 % len(inputs)])
-            rate = 2 * Bs / (time.perf_counter() - t0)
+            t0, n = time.perf_counter(), 0
+            while n < 2 or time.perf_counter() - t0 < 0.6:   # at least two ticks and 0.6 s per candidate: a two-tick sample was noise-sized
+                ob.step(0.01 * (n + 1), inputs[(n + 1) % len(inputs)])
+                n += 1
+            rate = n * Bs / (time.perf_counter() - t0)
             search[str(nthreads)] = round(rate)
             if rate > best_rate:
                 best_threads, best_rate = nthreads, rate
@@ -272,6 +337,23 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
     finally:
         O.set_qp_mode(0)
     return out
+
+
+def gpu_sclk_mhz():
+    """Current shader clock of the first GPU in MHz from sysfs (the active `*` line of pp_dpm_sclk), or None when the box does
+    not expose it to this user."""
+    import glob
+    import re
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            for line in open(path):
+                if line.rstrip().endswith("*"):
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
+                    if m:
+                        return int(m.group(1))
+        except OSError:
+            continue
+    return None
 
 
 def dropin_latency(cfg, calls=300):
@@ -405,6 +487,7 @@ def main():
     ap.add_argument("--ring", type=int, default=RING, help="state slabs in the input ring")
     ap.add_argument("--jitter", type=float, default=0.1, help="amplitude of the per-tick input variation")
     ap.add_argument("--no-extras", action="store_true", help="skip the static-input and PCIe-inclusive side measurements")
+    ap.add_argument("--sustain-s", type=float, default=5.0, help="seconds of back-to-back ticks behind config.sustained_steps_per_s (0 = skip; part of the extras)")
     args = ap.parse_args()
     if args.random_schedule:
         args.lookahead = True
@@ -480,8 +563,12 @@ def main():
     gait = synthetic.random_gaits(B, cfg, seed=rank) if args.random_schedule else None
     state, cmd, t_off, slabs = make_input_ring(cfg, B, rank, device, ring, args.jitter, fixed_cmd, gait, args.random_schedule, args.chain_geometry)
     gathered = torch.empty(total_robots, 60, dtype=torch.float32, device=device) if dist is not None else None
+    gather_bufs = None
+    if dist is not None and args.total_batch is not None:   # uneven shards travel padded: staged in persistent buffers, nothing allocated in the timed loop
+        from robot_gym_amd.core.sharding import GatherBuffers
+        gather_bufs = GatherBuffers(args.total_batch, world, 60, torch.float32, device)
 
-    def run(slab_list, steps, warmup, events, cfg_run=None, allgather=None):
+    def run(slab_list, steps, warmup, events, cfg_run=None, allgather=None, clock_probe=None):
         """`warmup` untimed then `steps` timed ticks on a fresh controller; returns (seconds, handle-side profile, stats).
         allgather: "ring" / "direct" -- every step also all-gathers the [B, 60] action slab over the process group (RCCL over
         xGMI) with that schedule (core/sharding.py)."""
@@ -496,7 +583,7 @@ def main():
         def one_step(k):
             act = ctl.get_action(0.01 * k, slab_list[k % nslab])
             if allgather:
-                all_gather_actions(act, out=gathered, schedule=allgather, total=(args.total_batch if args.total_batch is not None else None))
+                all_gather_actions(act, out=gathered, schedule=allgather, total=(args.total_batch if args.total_batch is not None else None), buffers=gather_bufs)
 
         for k in range(warmup):
             one_step(k)
@@ -511,6 +598,8 @@ def main():
         t0 = time.perf_counter()
         for k in range(steps):
             one_step(warmup + k)
+            if clock_probe is not None and k in (steps // 100, steps // 2, steps - 1):   # (the host runs ahead of the GPU by its queue depth only)
+                clock_probe.append(gpu_sclk_mhz())
         sync()
         if dist is not None:
             dist.barrier()
@@ -561,7 +650,7 @@ def main():
     #    prediction from the previous tick is then perfect)
     #  - PCIe-inclusive rate: the gym side holds the robot state on the host -- pinned buffers, one upload of all inputs
     #    and one download of the action slab per tick
-    pcie_value = static_value = cold_value = steady_value = dropin_us = None
+    pcie_value = static_value = cold_value = steady_value = dropin_us = audit_off_value = sustained = None
     if world == 1 and dist is None and not args.no_extras and not dry:
         from robot_gym_amd.controllers.mpc.batched import PackedState
         names_io = ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact")
@@ -596,6 +685,21 @@ def main():
         ctl.close()
         el_ss, _, _, _, ctl = run(slabs, 200, 20, False)
         steady_value = B * 200 / el_ss
+        # what the audit lane costs this workload: the same 200 ticks without it
+        if cfg.audit_k > 0:
+            import dataclasses
+            ctl.close()
+            el_na, _, _, _, ctl = run(slabs, 200, 20, False, dataclasses.replace(cfg, audit_k=0))
+            audit_off_value = B * 200 / el_na
+        # sustained load: >= args.sustain_s seconds of back-to-back ticks (clocks and power settle on that time scale, and the
+        # driver's SMI sampler sees the GPU busy), with the shader clock read at the start, in the middle and at the end
+        if args.sustain_s > 0:
+            nticks = int(min(2_000_000, max(200, args.sustain_s * 1.05 / (el_ss / 200))))
+            ctl.close()
+            clocks = []
+            el_su, _, _, _, ctl = run(slabs, nticks, 20, False, clock_probe=clocks)
+            sustained = {"steps_per_s": B * nticks / el_su, "seconds": round(el_su, 2), "ticks": nticks,
+                         "vs_value_pct": None, "sclk_mhz": clocks or None}
         if B == 1:
             try:
                 dropin_us = dropin_latency(cfg)
@@ -649,7 +753,11 @@ def main():
                        "input_schedule": ("one frozen state slab (static inputs)" if ring == 1 else
                                           f"ring of {ring} state slabs resident in HBM, one per tick: v_world / rpy_rate scaled by 1 +- {args.jitter}, roll/pitch +- {0.2 * args.jitter:.3g} rad, foot positions +- {20 * args.jitter:.3g} %, measured contacts following the gait"),
                        "static_inputs": ring == 1, "static_inputs_steps_per_s": static_value, "cold_start_steps_per_s": cold_value,
-                       "steady_state_steps_per_s": steady_value, "dropin_get_action_latency_us": dropin_us,
+                       "steady_state_steps_per_s": steady_value, "audit_off_steady_state_steps_per_s": audit_off_value,
+                       "audit_cost_pct": (round(100.0 * (1.0 - steady_value / audit_off_value), 2) if (audit_off_value and steady_value) else None),
+                       "sustained_steps_per_s": (sustained["steps_per_s"] if sustained else None),
+                       "sustained": (dict(sustained, vs_value_pct=round(100.0 * sustained["steps_per_s"] / value, 1)) if sustained else None),
+                       "dropin_get_action_latency_us": dropin_us,
                        "robot": cfg.robot,
                        "solver": {0: "ADMM only", 1: "exact active set for every robot", 2: "ADMM + exact re-solve", 3: "hybrid: exact active set (1-2 stance legs), ADMM + exact re-solve (3-4)"}[cfg.solver]
                                  + f"; admm rho={cfg.admm_rho} (x{cfg.admm_rho34_scale} wrench body) relax={cfg.admm_relax} tol={cfg.admm_tol} check={cfg.admm_check} cap={cfg.admm_iters}" + (f" second stage rho={cfg.admm_rho2} after {cfg.admm_switch}" if args.lookahead else ""),
@@ -664,7 +772,7 @@ def main():
                        "audit": audit,
                        "pcie_inclusive_steps_per_s": pcie_value,
                        "sharding": (f"{world} x {B} robots" if args.total_batch is None else f"{total_robots} robots over {world} ranks (shard_bounds: {total_robots // world} or {total_robots // world + 1} each)") + ", no data-path collective",
-                       "kernel_sources": source_hash()},
+                       "kernel_sources": source_hash(), "commit": git_head()[0]},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profile(prof, names[dom]),
                          "units_per_launch": units[dom], "algorithmic_bytes_per_unit": round(algo_bytes_launch / max(units[dom], 1), 1),
@@ -686,19 +794,28 @@ def main():
         print(json.dumps(out), flush=True)
 
     # The direct (point-to-point) all-gather schedule has only ever run over gloo (no multi-GPU node was reachable): it is timed
-    # LAST and under a watchdog, so that a hang or an error in it cannot cost the run its line -- after the deadline rank 0
-    # prints the line without that number and every rank leaves.
-    if dist is not None and "direct" not in ag_elapsed and os.environ.get("RG_BENCH_DIRECT_ALLGATHER", "1") != "0":
-        import threading
-        finished = threading.Event()
+    # LAST and under a watchdog, so that a hang in it cannot cost the run its line -- after the deadline rank 0 prints the line
+    # without that number and every rank leaves with a NON-ZERO code (a run that lost a measurement to a hang did not succeed;
+    # self_launch relays the line and the code).  The line is printed exactly once (lock + flag), and the watchdog stays armed
+    # until the process group is gone: a rank whose own pass failed can still block in destroy_process_group on hung peers.
+    import threading
+    emit_lock, emitted = threading.Lock(), [False]
 
+    def emit_once():
+        with emit_lock:
+            if not emitted[0]:
+                emitted[0] = True
+                emit_line()
+
+    finished = threading.Event()
+    if dist is not None and "direct" not in ag_elapsed and os.environ.get("RG_BENCH_DIRECT_ALLGATHER", "1") != "0":
         def watchdog():
             if not finished.wait(float(os.environ.get("RG_BENCH_DIRECT_TIMEOUT_S", "120"))):
                 nonlocal ag_note
-                ag_note = "the direct all-gather pass did not finish within its deadline"
+                ag_note = "the direct all-gather pass (or the shutdown after it) did not finish within its deadline"
                 if rank == 0:
-                    emit_line()
-                os._exit(0)
+                    emit_once()
+                os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
@@ -707,12 +824,12 @@ def main():
             ag_elapsed["direct"] = max_over_ranks(e_)
         except Exception as e:   # reported, never fatal for the line
             ag_note = f"direct all-gather pass failed: {type(e).__name__}: {e}"
-        finished.set()
     if rank == 0:
-        emit_line()
+        emit_once()
     ctl.close()
     if dist is not None:
         dist.destroy_process_group()
+    finished.set()
 
 
 if __name__ == "__main__":

@@ -25,10 +25,27 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_actions(local_action, group=None, out=None, schedule="ring", total=None):
+class GatherBuffers:
+    """Persistent staging for all_gather_actions with uneven shards (`total` given): the padded local slab and the
+    padded [world * rows, width] receive array, allocated once so that a timed loop does not allocate per call."""
+
+    def __init__(self, total, world, width, dtype, device):
+        self.total, self.world, self.width = int(total), int(world), int(width)
+        self.rows = max(hi - lo for lo, hi in (shard_bounds(total, r, world) for r in range(world)))
+        self.local = torch.zeros(self.rows, width, dtype=dtype, device=device)
+        self.padded = torch.empty(world * self.rows, width, dtype=dtype, device=device)
+
+
+def _global_rank(dist, group, r):
+    """P2POp peers are GLOBAL ranks; `r` is a rank inside `group` (None = the default group, where the two coincide)."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def all_gather_actions(local_action, group=None, out=None, schedule="ring", total=None, buffers=None):
     """local_action: [b, 60] on this rank.  Returns the concatenated [sum b, 60] array on every rank.
     Equal b on all ranks unless `total` is given: then rank r holds shard_bounds(total, r, world) robots (slabs that
-    differ by one row travel padded to the largest one).  schedule: "ring" | "direct" (module docstring)."""
+    differ by one row travel padded to the largest one; `buffers`: a GatherBuffers to stage them in without allocating).
+    schedule: "ring" | "direct" (module docstring).  `group`: any process group; ranks below are ranks inside it."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if schedule not in ("ring", "direct"):
@@ -41,18 +58,29 @@ def all_gather_actions(local_action, group=None, out=None, schedule="ring", tota
         rows = max(hi - lo for lo, hi in bounds)
         if local_action.shape[0] != bounds[rank][1] - bounds[rank][0]:
             raise ValueError(f"rank {rank} holds {local_action.shape[0]} robots, its shard of {total} is {bounds[rank][1] - bounds[rank][0]}")
+        if buffers is not None and (buffers.total != total or buffers.world != world or buffers.width != width):
+            raise ValueError("GatherBuffers were sized for another (total, world, width)")
     local = local_action.contiguous()
     if bounds is not None and local.shape[0] < rows:   # pad the short slabs
-        local = torch.cat([local, local.new_zeros(rows - local.shape[0], width)])
-    padded = out if (out is not None and bounds is None) else torch.empty(world * rows, width, dtype=local.dtype, device=local.device)
+        if buffers is not None:
+            buffers.local[:local.shape[0]].copy_(local)
+            local = buffers.local
+        else:
+            local = torch.cat([local, local.new_zeros(rows - local.shape[0], width)])
+    if out is not None and bounds is None:
+        padded = out
+    elif buffers is not None and bounds is not None:
+        padded = buffers.padded
+    else:
+        padded = torch.empty(world * rows, width, dtype=local.dtype, device=local.device)
     chunks = list(padded.chunk(world, dim=0))
     if schedule == "direct" and world > 1:
         chunks[rank].copy_(local)
         ops = []
         for step in range(1, world):   # peers in rotated order: rank r starts with r + 1, so no link is everybody's first target
             dst, src = (rank + step) % world, (rank - step) % world
-            ops.append(dist.P2POp(dist.isend, local, dst, group))
-            ops.append(dist.P2POp(dist.irecv, chunks[src], src, group))
+            ops.append(dist.P2POp(dist.isend, local, _global_rank(dist, group, dst), group))
+            ops.append(dist.P2POp(dist.irecv, chunks[src], _global_rank(dist, group, src), group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     elif local.is_cuda:

@@ -52,6 +52,38 @@ def test_all_gather_actions_world_size_2_gloo(tmp_path):
     assert [open(tmp_path / f"r{r}").read() for r in range(2)] == ["ok", "ok"]
 
 
+def _subgroup_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from robot_gym_amd.core.sharding import GatherBuffers
+    grp = dist.new_group([1, 2])   # group ranks 0, 1 are GLOBAL ranks 1, 2: point-to-point peers must be mapped
+    ok = True
+    if rank in (1, 2):
+        gr = dist.get_rank(grp)
+        full = torch.arange(21 * 60, dtype=torch.float32).view(21, 60)
+        lo, hi = shard_bounds(21, gr, 2)    # uneven: 11 + 10 robots
+        bufs = GatherBuffers(21, 2, 60, torch.float32, "cpu")
+        out = torch.empty(21, 60)
+        for schedule in ("direct", "ring"):
+            for _ in range(2):   # the staging buffers are reused
+                got = all_gather_actions(full[lo:hi].clone(), group=grp, out=out, schedule=schedule, total=21, buffers=bufs)
+                ok = ok and got is out and torch.equal(got, full)
+        ok = ok and torch.equal(all_gather_actions(full[10 * gr:10 * gr + 10].clone(), group=grp, schedule="direct"), full[:20])
+    with open(os.path.join(tmp, f"r{rank}"), "w") as f:
+        f.write("ok" if ok else "bad")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_actions_on_a_subgroup_world_size_3_gloo(tmp_path):
+    """The direct schedule's point-to-point peers are global ranks: on a process group that is a SUBSET of the ranks the
+    group-relative indices must be mapped (they used to be passed as they were: wrong peers, a hang)."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_subgroup_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert [open(tmp_path / f"r{r}").read() for r in range(3)] == ["ok", "ok", "ok"]
+
+
 def test_bench_launches_its_own_ranks_dry_run_world_size_2():
     """`python bench.py --gpus 2` without RANK in the environment must start its own ranks (the driver's form for the
     scaling runs): a fresh torch.distributed.run child with two processes.  --dry-launch runs the whole protocol on CPU over

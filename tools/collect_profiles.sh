@@ -4,12 +4,13 @@
 #   stats: only the --kernel-trace --stats pass (and the bench line);  full (default): + HBM / SQ / f64 counter passes.
 # Summarise with tools/summarize_profiles.py <tag>.  The program after `--` is python3 itself (no env/bash hop).
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 MODE=${2:-full}
 shift; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python3 $ROOT/tools/evidence_guard.py > $OUT/evidence_header.txt || { cat $OUT/evidence_header.txt; exit 1; }   # the sources must be a commit's
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $*"
 echo "$BENCH" > $OUT/command.txt

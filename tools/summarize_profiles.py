@@ -9,7 +9,7 @@ so the raw value is reported and the 2x-corrected value is given as an upper bou
 import collections, csv, glob, json, os, shutil, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"       # r4 (headline) or r4_<workload key>: bench.py profile_tag()
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"       # r4 (headline) or r4_<workload key>: bench.py profile_tag()
 workload_key = tag.split("_", 1)[1] if "_" in tag else "headline"
 src = os.path.join("gpurun_out", f"prof_{tag}")
 dst = "profiles"
@@ -58,7 +58,10 @@ bl = os.path.join(src, "bench_line.json")
 meta = json.loads(open(bl).read()) if os.path.exists(bl) and os.path.getsize(bl) else {}
 import bench
 cmd_file = os.path.join(src, "command.txt")
-json.dump({"tag": tag, "workload_key": workload_key, "source_hash": bench.source_hash(),
+stamp = os.path.join(src, "evidence_header.txt")   # written on the GPU box by collect_profiles.sh (tools/evidence_guard.py)
+header = open(stamp).read().strip() if os.path.exists(stamp) else bench.evidence_header()
+json.dump({"tag": tag, "workload_key": workload_key, "source_hash": header.split("kernel sources ")[1].split()[0],
+           "commit": header.split("commit ")[1].split()[0], "evidence_header": header,
            "batch": (meta.get("config", {}).get("workload", "batch=4096").split("batch=")[1].split(" ")[0]),
            "command": (open(cmd_file).read().strip() if os.path.exists(cmd_file) else "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras") + " (under rocprofv3)", "traffic": traffic,
            "bench_line_under_profiler": meta}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
