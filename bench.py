@@ -479,6 +479,7 @@ def main():
     ap.add_argument("--rho2", type=float, default=None, help="second-stage ADMM rho of the contact-schedule body (0 = single stage)")
     ap.add_argument("--switch", type=int, default=None, help="first-stage iteration count of the contact-schedule body")
     ap.add_argument("--no-kernel-events", action="store_true", help="diagnostic: do not record per-kernel HIP events in the timed region (roofline.kernel_ms is then empty)")
+    ap.add_argument("--lane-grid", type=int, default=None, help="lanes per robot of the default plan's QP launch at horizon 10: 1 = one wave, 2 = 256 lanes, 0 / unset = by batch size (rg_mpc_config.lane_grid)")
     ap.add_argument("--horizon", type=int, default=HORIZON, help="MPC horizon (10 = the headline workload; 20 = BASELINE configs[4] shape)")
     ap.add_argument("--lookahead", action="store_true", help="opt-in contact-schedule extension (per-step contacts from the open-loop gait)")
     ap.add_argument("--random-schedule", action="store_true", help="BASELINE configs[4]: per-robot duty ~ U(0.5, 0.8) and a caller-supplied contact schedule with 10 %% drop-outs, re-drawn every tick (implies --lookahead)")
@@ -551,6 +552,8 @@ def main():
         over["kin_mode"] = args.kin_mode
     if args.audit_k is not None:
         over["audit_k"] = args.audit_k
+    if args.lane_grid is not None:
+        over["lane_grid"] = args.lane_grid
     cfg = MPCConfig.for_robot(args.robot, horizon=args.horizon, **over)
     B = args.batch
     total_robots = world * B

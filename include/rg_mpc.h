@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RG_MPC_ABI_VERSION 4
+#define RG_MPC_ABI_VERSION 5
 #define RG_MPC_MAX_HORIZON 20
 #define RG_MPC_NUM_LEGS 4
 #define RG_MPC_NUM_MOTORS 12
@@ -152,7 +152,25 @@ typedef struct {
                                (RG_SOLVER_HYBRID) these robots are the launch's longest jobs */
   double admm_rho_sched_scale; /* the same for the schedule body (any contact schedule; three and four legs at horizon 20), which
                                iterates in wrench space too */
+  int32_t lane_grid;        /* lanes per robot in the QP launch of the default plan at horizon 10: 1 = one 64-lane wave (8 x 8 lanes,
+                               8 x 8 register tiles); 2 = 256 lanes (16 x 16 lanes, 4 x 4 tiles): a robot's dependent chain is
+                               ~a third shorter, its wave-slot time larger -- for batches that leave most of the chip idle;
+                               0 = chosen by rg_mpc_create from the batch (2 up to RG_MPC_WIDE_BATCH robots).  Ignored by
+                               the other plans and at horizon 20 (always 256 lanes) */
+  /* Recall-sensitive conventions.  The MPC arithmetic of the reference lives in an un-vendored package (motion_imitation
+   * 0.0.5, reference requirements.txt:8) and is restated here from recall.  Where the recall has two
+   * plausible readings, the reading is a switch: 0 = what this library and its oracle implement by default, 1 = the other
+   * one, so that a maintainer who can run the upstream package (tests/golden/make_upstream_golden.py) flips a convention
+   * without touching a kernel. */
+  int32_t conv_alpha_doubled;   /* 0: P = 2 B'WB + alpha I ; 1: P = 2 (B'WB + alpha I), i.e. the regulariser inside the factor 2 */
+  int32_t conv_feet_rotation;   /* lever arms r_i = R foot_i with yaw zeroed: 0: R = Rx(roll) Ry(pitch) ; 1: R = Ry(pitch) Rx(roll), the
+                                   order the body inertia is rotated with */
+  int32_t conv_com_height;      /* CoM height from the contact feet: 0: |mean z| ; 1: mean |z| */
+  int32_t conv_first_latch;     /* 0: the first update after a reset does NOT latch a swing foot on a STANCE->SWING edge ; 1: it does */
+  int32_t conv_window_divide;   /* velocity filter while its window fills: 0: divide by the window size ; 1: by the samples held */
+  int32_t reserved4;        /* must be 0 */
 } rg_mpc_config;
+#define RG_MPC_WIDE_BATCH 1024
 
 /* Device pointers, float32 / int32, component-major [c][B].  Reference getters named per
  * field (model/robots/robot.py). */

@@ -81,6 +81,14 @@ class MPCConfig:
     audit_tol: float = 1e-4      # per-robot torque error the audit counts as over tolerance
     admm_rho34_scale: float = 0.5   # first-stage rho of the wrench-space ADMM body (three / four legs, horizon 10) = admm_rho x this: its iteration count falls with rho at every percentile (1.0: mean 54, 0.5: 43; measured 0.3 ... 1.0, profiles/r4_rho34.txt)
     admm_rho_sched_scale: float = 1.0   # the same for the schedule body (contact schedules; three / four legs at horizon 20)
+    lane_grid: int = 0           # lanes per robot in the default plan's QP launch at horizon 10: 0 = by batch size, 1 = one wave, 2 = 256 lanes (rg_mpc.h)
+    # recall-sensitive conventions: 0 = this library's default reading, 1 = the other plausible one
+    conv_alpha_doubled: int = 0      # 1: P = 2 (B'WB + alpha I)
+    conv_feet_rotation: int = 0      # 1: lever arms rotated with Ry(pitch) Rx(roll) like the inertia
+    conv_com_height: int = 0         # 1: mean |z| of the contact feet instead of |mean z|
+    conv_first_latch: int = 0        # 1: the first update after a reset latches swing feet too
+    conv_window_divide: int = 0      # 1: the filling velocity window divides by the samples held
+    reserved4: int = 0
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

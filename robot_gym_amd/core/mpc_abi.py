@@ -12,7 +12,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csrc")
 # RG_MPC_LIB: load another build of the same C-ABI (kernel A/B experiments); never a fallback
 LIB_PATH = os.environ.get("RG_MPC_LIB") or os.path.abspath(os.path.join(_CSRC, "librg_mpc.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 AUDIT_PERIOD = 8   # RG_MPC_AUDIT_PERIOD: the audit lane picks on the first tick and then on every 8th one (ticks 4, 12, 20 ...)
 d = C.c_double
 i32 = C.c_int32
@@ -39,6 +39,8 @@ class CConfig(C.Structure):
         ("admm_rho2", d), ("admm_switch", i32), ("admm_accel", i32), ("admm_extrap", d),
         ("accel_cos2", d), ("accel_rmax", d), ("accel_rmin", d), ("accel_rate_cap", d),
         ("audit_k", i32), ("reserved3", i32), ("audit_tol", d), ("admm_rho34_scale", d), ("admm_rho_sched_scale", d),
+        ("lane_grid", i32), ("conv_alpha_doubled", i32), ("conv_feet_rotation", i32), ("conv_com_height", i32), ("conv_first_latch", i32),
+        ("conv_window_divide", i32), ("reserved4", i32),
     ]
 
 

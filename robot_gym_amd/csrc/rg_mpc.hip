@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -96,7 +97,8 @@ struct rg_mpc_handle {
   int prof_max = 0, prof_n = 0, prof_stride = 1;   // events are recorded on every prof_stride-th step
   long long tick = 0;
   bool fused = false;               // one QP launch for all stance-leg counts, work order = the front kernel's cost classes (every plan except exact + contact schedule)
-  bool exact12 = false;             // ... in which one- and two-leg robots run the exact active-set body (RG_SOLVER_HYBRID / RG_SOLVER_ACTIVE_SET, horizon 10, constant contacts)
+  bool exact12 = false;             // ... in which one- and two-leg robots run the exact active-set body (RG_SOLVER_HYBRID / RG_SOLVER_ACTIVE_SET, constant contacts)
+  bool wide = false;                // ... on 256 lanes per robot instead of one wave (horizon 10, hybrid plan: rg_mpc_config.lane_grid)
   int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO: robots ADMM left unconverged are re-solved exactly
   int retry_max_nc = 0;             // ... for robots with up to this many stance legs
@@ -213,7 +215,10 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   // the reference cannot set the horizon at all (mpc_controller.py:47-56 passes none: upstream default 10); 10 and 20
   // (BASELINE configs[4]) are the horizons with compiled and GPU-tested solver bodies
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
-  if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0 || c->reserved4 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (c->lane_grid < 0 || c->lane_grid > 2) { err = "lane_grid must be 0 (by batch), 1 (one wave per robot) or 2 (256 lanes per robot)"; return RG_MPC_ERR_INVALID; }
+  for (int v : {c->conv_alpha_doubled, c->conv_feet_rotation, c->conv_com_height, c->conv_first_latch, c->conv_window_divide})
+    if (v != 0 && v != 1) { err = "convention switches (conv_*) are 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (!(c->accel_cos2 > 0 && c->accel_cos2 < 1) || !(c->accel_rmin > 0 && c->accel_rmin < c->accel_rmax && c->accel_rmax < 1) || !(c->accel_rate_cap > 0 && c->accel_rate_cap < 1)) { err = "extrapolation thresholds out of range: 0 < accel_cos2 < 1, 0 < accel_rmin < accel_rmax < 1, 0 < accel_rate_cap < 1"; return RG_MPC_ERR_INVALID; }
   if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / (2 * RG_AUDIT_PERIOD) || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0 || !(c->admm_rho34_scale > 0 && c->admm_rho34_scale <= 10) || !(c->admm_rho_sched_scale > 0 && c->admm_rho_sched_scale <= 10)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
@@ -230,7 +235,9 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
     if (c->init_state[i] != RG_LEG_SWING && c->init_state[i] != RG_LEG_STANCE) { err = "init_state must be SWING or STANCE"; return RG_MPC_ERR_INVALID; }
   }
   d->H = c->horizon; d->window = c->window; d->kin_mode = c->kin_mode; d->ik_iters = c->ik_iters; d->admm_iters = c->admm_iters; d->accel_from = c->admm_accel; d->accel_k[0] = c->accel_cos2; d->accel_k[1] = c->accel_rmax; d->accel_k[2] = c->accel_rmin; d->accel_k[3] = c->accel_rate_cap; d->audit_tol = c->audit_tol;
-  d->dt = c->dt_plan; d->mass = c->mass; d->inv_mass = 1.0 / c->mass; d->body_height = c->body_height; d->alpha = c->alpha;
+  d->dt = c->dt_plan; d->mass = c->mass; d->inv_mass = 1.0 / c->mass; d->body_height = c->body_height;
+  d->alpha = c->conv_alpha_doubled ? 2.0 * c->alpha : c->alpha;   // P = 2 (B'WB + alpha I) is the default form with twice the regulariser
+  d->conv_feet_rotation = c->conv_feet_rotation; d->conv_com_height = c->conv_com_height; d->conv_first_latch = c->conv_first_latch; d->conv_window_divide = c->conv_window_divide;
   d->mu = c->mu[0]; d->g = c->gravity;
   d->fz_min = c->mass * c->gravity * c->fz_min_scale; d->fz_max = c->mass * c->gravity * c->fz_max_scale;
   {
@@ -307,7 +314,12 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   //     (qp_exact_wrench_robot); the re-solve launch only sees a working set that overflowed or a degenerate stance.  With
   //     a contact schedule every robot goes to the re-solve launch directly (front kernel plan 0: list = stance-leg bin).
   const bool as_only = cfg->solver == RG_SOLVER_ACTIVE_SET;
-  h->exact12 = (cfg->solver == RG_SOLVER_HYBRID || as_only) && cfg->horizon == 10 && !cfg->contact_lookahead;
+  // (horizon 20: the hybrid plan has its exact body for one / two legs too -- 256 lanes, the solve on one wave of them)
+  h->exact12 = ((cfg->solver == RG_SOLVER_HYBRID || as_only) && cfg->horizon == 10 && !cfg->contact_lookahead) ||
+               (cfg->solver == RG_SOLVER_HYBRID && cfg->horizon == 20 && !cfg->contact_lookahead);
+  // lanes per robot of the default plan's QP launch at horizon 10 (rg_mpc_config.lane_grid)
+  h->wide = cfg->solver == RG_SOLVER_HYBRID && cfg->horizon == 10 && !cfg->contact_lookahead &&
+            (cfg->lane_grid == 2 || (cfg->lane_grid == 0 && batch <= RG_MPC_WIDE_BATCH));
   h->fused = !(as_only && cfg->contact_lookahead);
   h->auto_retry = cfg->solver != RG_SOLVER_ADMM;
   // exact re-solve body behind every robot the QP launch hands on: horizon 10 -- the four-leg force-space active-set body
@@ -511,7 +523,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // contact schedule has no QP launch of its own: the front kernel's stance-leg bins are the re-solve launch's direct lists)
   if (h->fused) {
     if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
-    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->dcfg, h->st, dout, B, s));
+    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->wide, h->dcfg, h->st, dout, B, s));
   } else {   // no QP launch to carry the swing IK lanes: a launch of their own
     hipLaunchKernelGGL(rg_swing_ik_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, dout, B);
     HIPCHK(h, hipGetLastError());

@@ -67,6 +67,7 @@ struct DevCfg {
                          // kernel entry and spilled to scratch by every workgroup
   double audit_tol;      // audit lane: per-robot torque error counted as over tolerance
   double admm_extrap;    // geometric-extrapolation convergence guard, in units of the movement tolerance (+inf = off)
+  int conv_feet_rotation, conv_com_height, conv_first_latch, conv_window_divide;   // recall-sensitive conventions (rg_mpc.h); alpha doubling is folded into `alpha`
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
 };
