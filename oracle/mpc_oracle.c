@@ -154,13 +154,15 @@ static void neumaier(double *sum, double *corr, double v) {
   if (fabs(*sum) >= fabs(v)) *corr += (*sum - ns) + v; else *corr += (v - ns) + *sum;
   *sum = ns;
 }
-double orc_filter_push(orc_state *s, int axis, int window, double v) {
+static double filter_push_div(orc_state *s, int axis, int window, double v, int by_samples) {
   /* ring_len/ring_head are advanced by the caller after all three axes were pushed */
   if (s->ring_len >= window) neumaier(&s->fsum[axis], &s->fcorr[axis], -s->ring[axis][s->ring_head]);
-  neumaier(&s->fsum[axis], &s->fcorr[axis], v);
   s->ring[axis][s->ring_head] = v;
-  return (s->fsum[axis] + s->fcorr[axis]) / (double)window;
+  neumaier(&s->fsum[axis], &s->fcorr[axis], v);
+  const int held = s->ring_len >= window ? window : s->ring_len + 1;   /* samples in the window after this push */
+  return (s->fsum[axis] + s->fcorr[axis]) / (double)(by_samples ? held : window);
 }
+double orc_filter_push(orc_state *s, int axis, int window, double v) { return filter_push_div(s, axis, window, v, 0); }
 
 /* ------------------------------------------------------------------------------------ */
 /* swing trajectory [UPSTREAM-RECALL raibert_swing_leg_controller._gen_swing_foot_trajectory] */
@@ -307,12 +309,13 @@ static void mpc_build_dense(const orc_config *c, const double rpy_in[3], const d
   /* feet to the world-aligned frame: AngleAxis(roll,X)*AngleAxis(pitch,Y)*AngleAxis(yaw,Z) */
   double rx[9], ry[9], rz[9], Rfeet[9], t9[9];
   rot_x(rpy[0], rx); rot_y(rpy[1], ry); rot_z(rpy[2], rz);
-  mat3_mul(rx, ry, t9); mat3_mul(t9, rz, Rfeet);
+  if (c->conv_feet_rotation) { mat3_mul(ry, rx, t9); mat3_mul(rz, t9, Rfeet); }   /* the inertia's order: Rz Ry Rx */
+  else { mat3_mul(rx, ry, t9); mat3_mul(t9, rz, Rfeet); }
   double fw[4][3];
   for (int i = 0; i < 4; i++) mat3_vec(Rfeet, &foot_pos[3 * i], fw[i]);
   /* EstimateCoMHeightSimple: |mean z of contact feet| */
   int ncontact = 0; double hz = 0;
-  for (int i = 0; i < 4; i++) if (contact[i]) { hz += fw[i][2]; ncontact++; }
+  for (int i = 0; i < 4; i++) if (contact[i]) { hz += c->conv_com_height ? fabs(fw[i][2]) : fw[i][2]; ncontact++; }
   double com_z = ncontact > 0 ? fabs(hz / ncontact) : 0.0;
   double x0[13] = {rpy[0], rpy[1], rpy[2], 0, 0, com_z, omega[0], omega[1], omega[2], v_body[0], v_body[1], v_body[2], -c->gravity};
   double *xd = ws_calloc((size_t)NX * H, sizeof(double));
@@ -390,7 +393,7 @@ static void mpc_build_dense(const orc_config *c, const double rpy_in[3], const d
     double s = 0; for (int r = 0; r < NR; r++) s += bqp[(size_t)r * NC + i] * WB[(size_t)r * NC + j];
     P[(size_t)i * NC + j] = 2 * s; P[(size_t)j * NC + i] = 2 * s;
   }
-  for (int i = 0; i < NC; i++) P[(size_t)i * NC + i] += c->alpha;
+  for (int i = 0; i < NC; i++) P[(size_t)i * NC + i] += (c->conv_alpha_doubled ? 2.0 : 1.0) * c->alpha;
   double *sd = ws_alloc(sizeof(double) * NR);
   for (int i = 0; i < H; i++) for (int r = 0; r < NX; r++) {
     double s = 0; for (int k = 0; k < NX; k++) s += aqp[(size_t)i * NX * NX + r * NX + k] * x0[k];
@@ -725,12 +728,12 @@ static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const 
   double t = t_now - s->reset_time;
   orc_gait(c, t, in->contact, s->desired, s->leg_state, s->phase);
   double vf[3];
-  for (int a = 0; a < 3; a++) vf[a] = orc_filter_push(s, a, c->window, in->v_world[a]);
+  for (int a = 0; a < 3; a++) vf[a] = filter_push_div(s, a, c->window, in->v_world[a], c->conv_window_divide);
   s->ring_head = (s->ring_head + 1) % c->window;
   if (s->ring_len < c->window) s->ring_len++;
   quat_inv_rotate(in->quat, vf, s->v_body);
   /* swing update: latch feet at desired STANCE->SWING transitions */
-  if (!s->first_update) {
+  if (!s->first_update || c->conv_first_latch) {
     for (int leg = 0; leg < 4; leg++)
       if (s->desired[leg] == ORC_SWING && s->desired[leg] != s->last_desired[leg]) memcpy(s->latched[leg], foot[leg], sizeof(double) * 3);
   }

@@ -70,6 +70,14 @@ typedef struct {
   /* --- input mode --- */
   int kin_mode;             /* 0: foot_pos + jac supplied; 1: computed from q by chain model */
   int contact_lookahead;    /* EXTENSION (not upstream): contact flags per horizon step from the open-loop gait at t + k*dt_plan */
+  /* --- recall-sensitive conventions [UPSTREAM-RECALL]: 0 = the reading restated here by default, 1 = the other plausible
+   * one (same switches as rg_mpc_config.conv_*; tests/golden/make_upstream_golden.py + tests/test_upstream_golden.py say
+   * which reading the upstream package has, on a machine where it can be imported) --- */
+  int conv_alpha_doubled;   /* 1: P = 2 (B'WB + alpha I) instead of 2 B'WB + alpha I */
+  int conv_feet_rotation;   /* 1: lever arms rotated with Ry(pitch) Rx(roll) (the inertia's order) instead of Rx(roll) Ry(pitch) */
+  int conv_com_height;      /* 1: mean |z| of the contact feet instead of |mean z| */
+  int conv_first_latch;     /* 1: the first update after a reset latches swing feet on a STANCE->SWING edge too */
+  int conv_window_divide;   /* 1: the velocity window divides by the samples held while it fills, instead of by its size */
 } orc_config;
 
 typedef struct {

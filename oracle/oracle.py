@@ -29,6 +29,7 @@ class Config(C.Structure):
         ("jxyz", ((d * 3) * 3) * 4), ("jrpy", ((d * 3) * 3) * 4), ("jaxis", ((d * 3) * 3) * 4),
         ("toe_xyz", (d * 3) * 4), ("toe_com", (d * 3) * 4), ("base_com", d * 3),
         ("ik_iters", i32), ("ik_damping", d), ("ik_max_step", d), ("kin_mode", i32), ("contact_lookahead", i32),
+        ("conv_alpha_doubled", i32), ("conv_feet_rotation", i32), ("conv_com_height", i32), ("conv_first_latch", i32), ("conv_window_divide", i32),
     ]
 
 

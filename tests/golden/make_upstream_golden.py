@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Pin the oracle to the UPSTREAM package -- on a machine that has it.
+
+The MPC arithmetic of the reference does not live in the reference tree: robot_gym/controllers/mpc/mpc_controller.py:6-7
+imports `mpc_controller` (gait generator, velocity estimator, Raibert swing controller, torque stance controller,
+locomotion controller) and, through the stance controller, the pybind11 module `mpc_osqp` -- both from
+motion_imitation==0.0.5 (reference requirements.txt:8).  No image of this project holds that package, so oracle/ restates
+it from recall and every parity claim of rows 14-20 of SURVEY.md section 8 is "HIP == this repository's restatement".
+This script closes that gap the day the package can be imported:
+
+    pip install motion_imitation==0.0.5                      # brings mpc_controller and mpc_osqp
+    RG_REFERENCE=/path/to/robot-gym python tests/golden/make_upstream_golden.py
+    python -m pytest tests/test_upstream_golden.py -q        # ORACLE vs these files (skipped while they are absent)
+
+It drives the UPSTREAM objects -- wired exactly as the reference wires them, through the reference's own MPCController
+class when RG_REFERENCE (or an installed robot_gym) provides it -- on seeded synthetic robot states served by a stub robot,
+and writes what they computed:
+
+    tests/golden/upstream_controller.npz   per case and tick: the inputs (state, contacts, clock, command) and the upstream
+                                           results: desired / actual leg states, normalised phases, body-frame CoM
+                                           velocity, the 60-float hybrid action, the swing foot targets handed to the IK
+    tests/golden/upstream_qp.npz           ConvexMpc.compute_contact_forces on seeded states: inputs and the returned forces
+    tests/golden/upstream_meta.json        package versions, constructor signatures seen, the cases
+
+Nothing of the upstream SOURCE is copied: the files hold inputs and outputs only.  The tests compare the oracle in every
+combination of the recall-sensitive conventions (rg_mpc_config.conv_*) and say which one the package
+has; `python tests/golden/make_upstream_golden.py --pin` then writes that combination to tests/golden/upstream_conventions.json.
+
+The joint-angle side of the swing legs (ComputeMotorAnglesFromFootLocalPosition) is PyBullet's IK in the reference
+(controllers/mpc/kinematics.py:98-133), not upstream arithmetic: the stub records the foot target it is asked for and
+answers with the current joint angles, so q* entries of the action rows are not part of these vectors.
+"""
+import argparse
+import inspect
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def import_upstream():
+    try:
+        import mpc_controller  # noqa: F401
+        from mpc_controller import (com_velocity_estimator, gait_generator, locomotion_controller, openloop_gait_generator,
+                                    raibert_swing_leg_controller, torque_stance_leg_controller)
+    except ImportError as e:
+        raise SystemExit(f"upstream package not importable ({e}): pip install motion_imitation==0.0.5 (reference requirements.txt:8)")
+    try:
+        import mpc_osqp
+    except ImportError:
+        mpc_osqp = None   # some builds ship it inside the package
+        try:
+            from mpc_controller import mpc_osqp  # type: ignore
+        except ImportError as e:
+            raise SystemExit(f"mpc_osqp (the pybind11 convex-MPC module of motion_imitation) not importable: {e}")
+    return dict(com_velocity_estimator=com_velocity_estimator, gait_generator=gait_generator, locomotion_controller=locomotion_controller,
+                openloop_gait_generator=openloop_gait_generator, raibert_swing_leg_controller=raibert_swing_leg_controller,
+                torque_stance_leg_controller=torque_stance_leg_controller, mpc_osqp=mpc_osqp)
+
+
+# ---- quaternion helpers standing in for the two pybullet calls the velocity estimator makes (x, y, z, w) ----
+def _q_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return (aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz)
+
+
+def _q_rot(q, v):
+    x, y, z, w = q
+    t = 2.0 * np.cross((x, y, z), v)
+    return np.asarray(v, dtype=np.float64) + w * t + np.cross((x, y, z), t)
+
+
+class _Bullet:
+    """invertTransform / multiplyTransforms / getEulerFromQuaternion with pybullet's conventions, in numpy."""
+
+    def invertTransform(self, pos, orn):
+        inv = (-orn[0], -orn[1], -orn[2], orn[3])
+        return tuple(-_q_rot(inv, pos)), inv
+
+    def multiplyTransforms(self, pa, oa, pb, ob):
+        return tuple(np.asarray(pa, dtype=np.float64) + _q_rot(oa, pb)), _q_mul(oa, ob)
+
+    def getEulerFromQuaternion(self, q):
+        x, y, z, w = q
+        return (np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y)), np.arcsin(np.clip(2 * (w * y - z * x), -1, 1)), np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z)))
+
+
+def make_robot(cfg, state):
+    """The reference's Robot surface (model/robots/robot.py:49-102,169-229,389-397) over one robot of a synthetic batch."""
+    from tests.fake_envs import StubRobot
+
+    class UpstreamRobot(StubRobot):
+        def __init__(self):
+            super().__init__(cfg, state, 0)
+            self.pybullet_client = _Bullet()
+            self.num_legs, self.num_motors = 4, 12
+            self.ik_targets = {}
+
+        def GetHipPositionsInBaseFrame(self): return np.array(cfg.hip).reshape(4, 3)                     # robot.py:169-170
+        def GetMotorPositionGains(self): return list(cfg.motor_kp)                                        # robot.py:88-92
+        def GetMotorVelocityGains(self): return list(cfg.motor_kd)
+        def GetFootContacts(self): return [bool(x) for x in self.contact]
+        def GetBaseVelocity(self): return tuple(float(x) for x in self.state["v_world"][:, self.b])
+        def GetTrueBaseOrientation(self): return tuple(float(x) for x in self.state["quat"][:, self.b])
+
+        def MapContactForceToJointTorques(self, leg_id, force):                                           # kinematics.py:40-53
+            J = self.state["jac"][:, self.b].reshape(4, 3, 3)[leg_id].astype(np.float64)
+            tau = np.asarray(force, dtype=np.float64) @ J
+            return {3 * leg_id + j: float(tau[j] * cfg.motor_dir[3 * leg_id + j]) for j in range(3)}
+
+        def ComputeMotorAnglesFromFootLocalPosition(self, leg_id, foot_position):                        # kinematics.py:98-133 (PyBullet IK: recorded, not computed)
+            self.ik_targets[leg_id] = np.asarray(foot_position, dtype=np.float64).copy()
+            ids = [3 * leg_id, 3 * leg_id + 1, 3 * leg_id + 2]
+            return ids, [float(self.state["q"][j, self.b]) for j in ids]
+
+    return UpstreamRobot()
+
+
+def build_controller(up, robot, clock, cfg):
+    """The reference's wiring: its own class when the reference is importable, else the same five constructor calls
+    (controllers/mpc/mpc_controller.py:28-66) with the arguments tests/golden/adapter.json pins."""
+    ref = os.environ.get("RG_REFERENCE")
+    if ref:
+        sys.path.insert(0, ref)
+    try:
+        from robot_gym.controllers.mpc.mpc_controller import MPCController   # the reference's adapter
+        ctl = MPCController(robot, clock)
+        return ctl, ctl._mpc_controller, "reference MPCController"
+    except Exception as e:   # no reference tree / no pybullet behind its imports: wire the upstream objects directly
+        how = f"direct wiring ({type(e).__name__}: {e})"
+    gait = up["openloop_gait_generator"].OpenloopGaitGenerator(robot, stance_duration=list(cfg.stance_duration), duty_factor=list(cfg.duty_factor),
+                                                                 initial_leg_phase=list(cfg.init_phase), initial_leg_state=[up["gait_generator"].LegState(s) for s in cfg.init_state])
+    est = up["com_velocity_estimator"].COMVelocityEstimator(robot, window_size=cfg.window)
+    sw = up["raibert_swing_leg_controller"].RaibertSwingLegController(robot, gait, est, desired_speed=(0.0, 0.0), desired_twisting_speed=0.0,
+                                                                     desired_height=cfg.body_height, foot_clearance=cfg.foot_clearance)
+    st = up["torque_stance_leg_controller"].TorqueStanceLegController(robot, gait, est, desired_speed=(0.0, 0.0), desired_twisting_speed=0.0,
+                                                                      desired_body_height=cfg.body_height, body_mass=cfg.mass, body_inertia=tuple(cfg.inertia))
+    loco = up["locomotion_controller"].LocomotionController(robot=robot, gait_generator=gait, state_estimator=est, swing_leg_controller=sw,
+                                                            stance_leg_controller=st, clock=clock)
+
+    class Direct:
+        _mpc_controller = loco
+
+        def update_controller_params(self, p):
+            vx, vy, wz = (p[0], 0.0, p[1]) if len(p) == 2 else p
+            lin = [vx + cfg.vx_offset, vy + cfg.vy_offset, 0.0]
+            for c in (sw, st):
+                c.desired_speed, c.desired_twisting_speed = lin, wz + cfg.wz_offset
+
+        def get_action(self):
+            loco.update()
+            return loco.get_action()
+
+        def reset(self): loco.reset()
+    return Direct(), loco, how
+
+
+def _attr(obj, *names):
+    for n in names:
+        if hasattr(obj, n):
+            v = getattr(obj, n)
+            return v() if callable(v) else v
+    return None
+
+
+def gen_controller(up, cases, ticks):
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd import synthetic
+    from tests import helpers
+    out, meta = {}, []
+    for ci, (robot_name, seed) in enumerate(cases):
+        cfg = MPCConfig.for_robot(robot_name)
+        state, cmd, t_off = synthetic.make_states(1, cfg, seed=seed)
+        robot = make_robot(cfg, state)
+        clock = [0.0]
+        ctl, loco, how = build_controller(up, robot, lambda: clock[0], cfg)
+        ctl.reset()
+        ctl.update_controller_params(tuple(float(x) for x in cmd[:, 0]))
+        rec = {k: [] for k in ("t", "rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac", "contact", "action", "desired", "leg_state", "phase", "v_body", "foot_target", "target_valid")}
+        for k in range(ticks):
+            st = helpers.perturb(state, k, 0.1)
+            robot.state = st
+            robot.contact = synthetic.gait_consistent_contacts(cfg, np.array([0.01 * k]), state["_flip"])[:, 0].astype(bool)   # (the controller's clock starts at its reset: no phase offset)
+            robot.ik_targets = {}
+            clock[0] = 0.01 * k
+            res = ctl.get_action()
+            action = np.asarray(res[0] if isinstance(res, tuple) else res, dtype=np.float64).reshape(60)
+            g = loco.gait_generator if hasattr(loco, "gait_generator") else loco._gait_generator
+            e = loco.state_estimator if hasattr(loco, "state_estimator") else loco._state_estimator
+            rec["t"].append(clock[0])
+            for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac"):
+                rec[n].append(np.asarray(st[n][:, 0], dtype=np.float64))
+            rec["contact"].append(robot.contact.astype(np.int32))
+            rec["action"].append(action)
+            rec["desired"].append(np.array([int(getattr(s, "value", s)) for s in _attr(g, "desired_leg_state")], dtype=np.int32))
+            rec["leg_state"].append(np.array([int(getattr(s, "value", s)) for s in _attr(g, "leg_state")], dtype=np.int32))
+            rec["phase"].append(np.asarray(_attr(g, "normalized_phase"), dtype=np.float64))
+            rec["v_body"].append(np.asarray(_attr(e, "com_velocity_body_frame"), dtype=np.float64))
+            tg, tv = np.zeros((4, 3)), np.zeros(4, dtype=np.int32)
+            for leg, p in robot.ik_targets.items():
+                tg[leg], tv[leg] = p, 1
+            rec["foot_target"].append(tg)
+            rec["target_valid"].append(tv)
+        for n, v in rec.items():
+            out[f"c{ci}_{n}"] = np.array(v)
+        out[f"c{ci}_cmd"] = np.asarray(cmd[:, 0], dtype=np.float64)
+        meta.append(dict(case=ci, robot=robot_name, seed=seed, ticks=ticks, wiring=how))
+    return out, meta
+
+
+def gen_qp(up, n_cases, rng):
+    """ConvexMpc.compute_contact_forces on seeded states.  The constructor's arity differs between releases of the
+    package: the signature found is recorded, and the call is made with as many of (mass, inertia, num_legs, horizon,
+    timestep, weights, alpha, solver) as it takes."""
+    from robot_gym_amd.core.config import MPCConfig
+    from robot_gym_amd import synthetic
+    cfg = MPCConfig.for_robot("ghost")
+    mod = up["mpc_osqp"]
+    args = [cfg.mass, list(cfg.inertia), 4, cfg.horizon, cfg.dt_plan, list(cfg.weights), cfg.alpha]
+    solver = getattr(mod, "QPOASES", None)
+    mpc, used = None, None
+    for k in (8, 7, 6):
+        try:
+            mpc = mod.ConvexMpc(*(args + [solver])[:k])
+            used = k
+            break
+        except TypeError:
+            continue
+    if mpc is None:
+        raise SystemExit("could not construct mpc_osqp.ConvexMpc with 6, 7 or 8 positional arguments: " + str(getattr(mod.ConvexMpc, "__doc__", "")))
+    state, cmd, _ = synthetic.make_states(n_cases, cfg, seed=7)
+    ins, outs = [], []
+    for b in range(n_cases):
+        contact = np.array([1, 1, 1, 1] if b % 3 == 0 else ([0, 1, 1, 0] if b % 3 == 1 else [1, 0, 0, 1]), dtype=np.int32)
+        rpy = state["rpy"][:, b].astype(np.float64).copy()
+        rpy[2] = 0.0   # the stance controller zeroes yaw before the call
+        v = rng.uniform(-0.5, 0.5, 3)
+        w = state["rpy_rate"][:, b].astype(np.float64)
+        feet = state["foot_pos"][:, b].astype(np.float64)
+        c3 = cmd[:, b].astype(np.float64)
+        f = mpc.compute_contact_forces([0.0], list(v), list(rpy), list(w), [int(x) for x in contact], list(feet), [cfg.mu[0]] * 4,
+                                       (0.0, 0.0, cfg.body_height), (c3[0], c3[1], 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, c3[2]))
+        ins.append(np.concatenate([v, rpy, w, contact, feet, c3]))
+        outs.append(np.asarray(f, dtype=np.float64))
+    return dict(inputs=np.array(ins), forces=np.array(outs), layout=np.array(["v_body[3] rpy[3] omega[3] contact[4] foot_pos[12] cmd(vx,vy,wz)[3]"])), dict(constructor_args_used=used, doc=str(getattr(mod.ConvexMpc, "__doc__", ""))[:2000])
+
+
+def pin():
+    """Run the comparison over all 32 convention settings and write the one that matches (tests/test_upstream_golden.py)."""
+    from tests.test_upstream_golden import best_conventions
+    conv, err = best_conventions()
+    json.dump(dict(conventions=conv, worst_error=err), open(os.path.join(HERE, "upstream_conventions.json"), "w"), indent=1)
+    print("upstream conventions:", conv, "worst error", err)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pin", action="store_true", help="after the vectors exist: find the conv_* setting under which the oracle matches them and write it to upstream_conventions.json")
+    ap.add_argument("--ticks", type=int, default=60)
+    args = ap.parse_args()
+    if args.pin:
+        return pin()
+    up = import_upstream()
+    rng = np.random.default_rng(20240)
+    cases = [("ghost", 11), ("ghost", 12), ("ghost", 13), ("k3lso", 21), ("k3lso", 22)]
+    ctrl, cmeta = gen_controller(up, cases, args.ticks)
+    np.savez_compressed(os.path.join(HERE, "upstream_controller.npz"), **ctrl)
+    qp, qmeta = gen_qp(up, 48, rng)
+    np.savez_compressed(os.path.join(HERE, "upstream_qp.npz"), **qp)
+    import importlib.metadata as md
+    ver = {}
+    for pkg in ("motion_imitation", "numpy", "pybullet"):
+        try:
+            ver[pkg] = md.version(pkg)
+        except Exception:
+            ver[pkg] = None
+    sigs = {}
+    for name in ("openloop_gait_generator.OpenloopGaitGenerator", "com_velocity_estimator.COMVelocityEstimator",
+                 "raibert_swing_leg_controller.RaibertSwingLegController", "torque_stance_leg_controller.TorqueStanceLegController"):
+        m, c = name.split(".")
+        try:
+            sigs[name] = str(inspect.signature(getattr(up[m], c).__init__))
+        except (TypeError, ValueError):
+            sigs[name] = None
+    json.dump(dict(versions=ver, signatures=sigs, controller_cases=cmeta, qp=qmeta), open(os.path.join(HERE, "upstream_meta.json"), "w"), indent=1)
+    print("wrote tests/golden/upstream_controller.npz, upstream_qp.npz, upstream_meta.json; now: python -m pytest tests/test_upstream_golden.py -q")
+
+
+if __name__ == "__main__":
+    main()

@@ -790,3 +790,43 @@ def test_every_robot_through_the_exact_resolve_kernel(oracle_lib, horizon, seed,
         assert stats["retried_exact"] >= 0.9 * sum(bins[1:]), (k, stats, bins)   # (a robot can converge within 8 iterations; hardly any does)
         m = helpers.compare_tick(g, orc[k])
         assert m["grf_rel_max"] <= 2e-5, (k, m)
+
+
+CONV_SWITCHES = ("conv_alpha_doubled", "conv_feet_rotation", "conv_com_height", "conv_first_latch", "conv_window_divide")
+
+
+@pytest.mark.parametrize("horizon", [10, 20])
+@pytest.mark.parametrize("switch", CONV_SWITCHES + ("all",))
+def test_recall_sensitive_conventions_are_config_switches(oracle_lib, switch, horizon):
+    """Every convention of the restated upstream arithmetic that has two plausible readings is an
+    rg_mpc_config field: in BOTH settings the HIP path matches the oracle with the same setting, and the setting is not
+    vacuous -- the oracle's own results differ between the two readings on these inputs.  (A maintainer who can import
+    the upstream package finds out which reading it has with tests/golden/make_upstream_golden.py and flips the switch,
+    no kernel is touched.)  Reference: requirements.txt:8 (motion_imitation==0.0.5 is where the arithmetic lives)."""
+    over = {n: 1 for n in CONV_SWITCHES} if switch == "all" else {switch: 1}
+    base = MPCConfig.for_robot("ghost", horizon=horizon, window=6)
+    cfg = MPCConfig.for_robot("ghost", horizon=horizon, window=6, **over)
+    state, cmd, t_off = synthetic.make_states(64, cfg, seed=41)
+    # mean |z| and |mean z| of the contact feet differ only when a contact foot is above the body origin: give a third of the
+    # robots one such foot (unphysical, but the convention has to be observable); roll / pitch of +-0.2 rad separate the two
+    # rotation orders; the short window and the start at reset make the first ticks depend on the filter and latch readings
+    fp = state["foot_pos"].copy()
+    fp[2, ::3] = np.float32(0.05)
+    state["foot_pos"] = fp
+    t_off = np.where(np.arange(64) % 2 == 0, 0.0, t_off)   # half of the robots start exactly at their reset
+    kw = dict(ticks=12, jitter=0.1)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, **kw)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, **kw)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
+    ref = helpers.run_oracle(oracle_lib, base, state, cmd, t_off, **kw)
+    diff = max(float(np.abs(a["action"].astype(np.float64) - b["action"].astype(np.float64)).max()) for a, b in zip(orc, ref))
+    if switch == "conv_first_latch":
+        # Not observable through this boundary: a reset robot latches ALL its feet at its first step (rg_mpc_reset: "swing start
+        # positions are latched from the foot positions of the first rg_mpc_step after the reset" -- in the reference flow the
+        # first get_action also sees the reset's own foot positions, gym/robot_gym_env.py:117-129 after core/simulation.py:123-127),
+        # so a STANCE->SWING edge on that step latches the same positions either way.  The oracle's orc_reset(foot_pos) shows
+        # the difference (tests/test_oracle_kat.py::test_first_update_latch_convention).
+        assert diff == 0.0, diff
+    else:
+        assert diff > 1e-3, (switch, diff)   # the other reading gives other commands: the test above would notice a switch that is not wired

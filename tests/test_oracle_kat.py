@@ -310,6 +310,39 @@ def test_first_update_after_reset_does_not_latch(oracle_lib):
     np.testing.assert_array_equal(np.array(ob.states[0].latched[1][:]), first)  # no transition seen -> unchanged
 
 
+def test_first_update_latch_convention(oracle_lib):
+    """conv_first_latch (a recall-sensitive convention): with the feet latched AT the reset
+    (orc_reset given foot positions) and the robot in another pose at its first update, the default reading keeps the
+    reset's latch through a STANCE->SWING edge seen by that first update; the other reading latches the current foot."""
+    O = oracle_lib
+    for conv in (0, 1):
+        base = MPCConfig.for_robot("ghost", init_phase=(0.0, 0.7, 0.0, 0.0), init_state=(1, 1, 1, 1), conv_first_latch=conv)
+        cfg = helpers.oracle_config(O, base)
+        ob = O.OracleBatch(cfg, 1)
+        inp = _static_input(O, cfg)
+        at_reset = np.array(inp["foot_pos"][0], dtype=np.float64)
+        ob.reset([0], 0.0, foot_pos=[at_reset.reshape(12)])
+        inp["foot_pos"][0][1] += (0.05, 0.0, 0.01)   # leg 1 has moved by the first update, which sees it go STANCE -> SWING
+        out = ob.step(0.0, inp)
+        assert list(out["desired"][0]) == [1, 0, 1, 1]
+        latched = np.array(ob.states[0].latched[1][:])
+        np.testing.assert_array_equal(latched, inp["foot_pos"][0][1] if conv else at_reset[1])
+
+
+def test_velocity_window_divide_convention(oracle_lib):
+    """conv_window_divide = 1: the filling window divides by the samples it holds (a plain moving average)."""
+    O = oracle_lib
+    cfg = helpers.oracle_config(O, MPCConfig.for_robot("ghost", duty_factor=(1.0,) * 4, init_phase=(0.0,) * 4, init_state=(1, 1, 1, 1), conv_window_divide=1))
+    ob = O.OracleBatch(cfg, 1)
+    inp = _static_input(O, cfg)
+    vs = np.random.default_rng(12).uniform(-1, 1, (30, 3))
+    for k in range(30):
+        inp["v_world"][0] = vs[k]
+        out = ob.step(0.01 * k, inp)
+        win = vs[max(0, k - 19):k + 1]
+        np.testing.assert_allclose(out["v_body"][0], np.array([math.fsum(win[:, a]) for a in range(3)]) / len(win), rtol=0, atol=1e-15)
+
+
 def test_contact_lookahead_extension(oracle_lib):
     """Opt-in extension: with a gait that never swings the look-ahead QP is the
     constant-contact QP; with a trot it differs, keeps swing legs force-free and satisfies the
