@@ -72,7 +72,8 @@ typedef struct {
   double body_height;       /* MPC_BODY_HEIGHT    ghost/ctrl_constants.py:10 */
   double weights[13];       /* upstream _MPC_WEIGHTS (rpy, xyz, omega, v, g) */
   double alpha;             /* 1e-5 ; P = 2 B'WB + alpha I */
-  double mu[4];             /* friction 0.45 x4 (must all be equal) */
+  double mu[4];             /* friction coefficient per leg (FR, FL, RR, RL); upstream's foot_friction_coeffs, 0.45 x 4 in the reference.
+                               Unequal values select kernel instantiations that carry the coefficient per lane */
   double fz_max_scale;      /* 10  : fz_max = scale * m * g */
   double fz_min_scale;      /* 0.1 : fz_min = scale * m * g */
   double gravity;           /* 9.8 */

@@ -781,7 +781,7 @@ static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const 
       double *P = ws_alloc(sizeof(double) * n * n), *qv = ws_alloc(sizeof(double) * n), *u = ws_alloc(sizeof(double) * n), *mu_blk = ws_alloc(sizeof(double) * nb);
       int *vs = ws_alloc(sizeof(int) * nb), *vl = ws_alloc(sizeof(int) * nb);
       orc_mpc_build_sched(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, sched, in->cmd, P, qv, vs, vl);
-      for (int b2 = 0; b2 < nb; b2++) mu_blk[b2] = c->mu[0];
+      for (int b2 = 0; b2 < nb; b2++) mu_blk[b2] = c->mu[vl[b2]];   /* the block's leg */
       double mg = c->mass * c->gravity;
       out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
       int bad = out->qp_iters < 0;
@@ -794,9 +794,11 @@ static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const 
     double *P = ws_alloc(sizeof(double) * n * n), *qv = ws_alloc(sizeof(double) * n), *u = ws_alloc(sizeof(double) * n), *mu_blk = ws_alloc(sizeof(double) * (n / 3));
     int legs[4];
     int nc = orc_mpc_build(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, in->cmd, P, qv, legs, NULL, NULL);
-    /* UpdateConstraintsMatrix uses friction_coeff[0..3] on the four cone ROWS of every block;
-     * all equal in every shipped config, so a per-block mu is equivalent. */
-    for (int b = 0; b < n / 3; b++) mu_blk[b] = c->mu[0];
+    /* mu[l] is LEG l's friction coefficient (what the name foot_friction_coeffs says).  [UPSTREAM-RECALL]: the package's
+     * UpdateConstraintsMatrix is recalled to put friction_coeff[0..3] on the four cone ROWS (-x, +x, -y, +y) of every block
+     * instead -- the same thing whenever the four are equal, as in every shipped config (0.45 x 4); with unequal values this
+     * restatement and the HIP path follow the per-leg meaning. */
+    for (int b = 0; b < n / 3; b++) mu_blk[b] = c->mu[legs[b % nc]];   /* blocks are ordered (step, contact-leg slot) */
     double mg = c->mass * c->gravity;
     out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
     if (out->qp_iters < 0) { return -1; }

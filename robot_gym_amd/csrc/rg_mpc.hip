@@ -99,6 +99,7 @@ struct rg_mpc_handle {
   bool fused = false;               // one QP launch for all stance-leg counts, work order = the front kernel's cost classes (every plan except exact + contact schedule)
   bool exact12 = false;             // ... in which one- and two-leg robots run the exact active-set body (RG_SOLVER_HYBRID / RG_SOLVER_ACTIVE_SET, constant contacts)
   bool wide = false;                // ... on 256 lanes per robot instead of one wave (horizon 10, hybrid plan: rg_mpc_config.lane_grid)
+  bool mu4 = false;                 // the four legs' friction coefficients differ: the kernel instantiations with a per-lane coefficient (leg_mu)
   int *counts2 = nullptr;           // [2][RG_NCOUNTS] double-buffered work-list counters
   bool auto_retry = false;          // RG_SOLVER_AUTO: robots ADMM left unconverged are re-solved exactly
   int retry_max_nc = 0;             // ... for robots with up to this many stance legs
@@ -223,7 +224,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / (2 * RG_AUDIT_PERIOD) || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0 || !(c->admm_rho34_scale > 0 && c->admm_rho34_scale <= 10) || !(c->admm_rho_sched_scale > 0 && c->admm_rho_sched_scale <= 10)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
-  if (!(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]) || !(c->mu[0] > 0)) { err = "friction coefficients must be equal and positive"; return RG_MPC_ERR_INVALID; }
+  for (int i = 0; i < 4; i++) if (!(c->mu[i] > 0 && c->mu[i] <= 100.0)) { err = "friction coefficients must be positive (and finite)"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO && c->solver != RG_SOLVER_HYBRID) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
@@ -239,6 +240,7 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   d->alpha = c->conv_alpha_doubled ? 2.0 * c->alpha : c->alpha;   // P = 2 (B'WB + alpha I) is the default form with twice the regulariser
   d->conv_feet_rotation = c->conv_feet_rotation; d->conv_com_height = c->conv_com_height; d->conv_first_latch = c->conv_first_latch; d->conv_window_divide = c->conv_window_divide;
   d->mu = c->mu[0]; d->g = c->gravity;
+  for (int i = 0; i < 4; i++) d->mu4[i] = c->mu[i];   // (per leg: read by the MU4 kernel instantiations only)
   d->fz_min = c->mass * c->gravity * c->fz_min_scale; d->fz_max = c->mass * c->gravity * c->fz_max_scale;
   {
     const double *I = c->inertia;
@@ -317,6 +319,7 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   // (horizon 20: the hybrid plan has its exact body for one / two legs too -- 256 lanes, the solve on one wave of them)
   h->exact12 = ((cfg->solver == RG_SOLVER_HYBRID || as_only) && cfg->horizon == 10 && !cfg->contact_lookahead) ||
                (cfg->solver == RG_SOLVER_HYBRID && cfg->horizon == 20 && !cfg->contact_lookahead);
+  h->mu4 = !(cfg->mu[0] == cfg->mu[1] && cfg->mu[1] == cfg->mu[2] && cfg->mu[2] == cfg->mu[3]);
   // lanes per robot of the default plan's QP launch at horizon 10 (rg_mpc_config.lane_grid)
   h->wide = cfg->solver == RG_SOLVER_HYBRID && cfg->horizon == 10 && !cfg->contact_lookahead &&
             (cfg->lane_grid == 2 || (cfg->lane_grid == 0 && batch <= RG_MPC_WIDE_BATCH));
@@ -513,7 +516,7 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (direct_now) {
     HIPCHK(h, hipEventRecord(h->front_done, s));
     HIPCHK(h, hipStreamWaitEvent(h->direct_stream, h->front_done, 0));
-    HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, h->direct_stream, RETRY_DIRECT));
+    HIPCHK(h, launch_qp_resolve_h10(h->mu4, h->dcfg, h->st, dout, B, h->cu_count, h->direct_stream, RETRY_DIRECT));
     HIPCHK(h, hipEventRecord(h->direct_done, h->direct_stream));
     h->direct_launches++;
   }
@@ -522,8 +525,8 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   // (a contact schedule puts every robot on the schedule body: its own launch, same work lists; the exact solver with a
   // contact schedule has no QP launch of its own: the front kernel's stance-leg bins are the re-solve launch's direct lists)
   if (h->fused) {
-    if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->dcfg, h->st, dout, B, s));
-    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->wide, h->dcfg, h->st, dout, B, s));
+    if (h->cfg.contact_lookahead) HIPCHK(h, launch_qp_sched_any(H, h->mu4, h->dcfg, h->st, dout, B, s));
+    else HIPCHK(h, launch_qp_fused_any(H, h->exact12 ? (h->cfg.solver == RG_SOLVER_ACTIVE_SET ? 2 : 1) : 0, h->wide, h->mu4, h->dcfg, h->st, dout, B, s));
   } else {   // no QP launch to carry the swing IK lanes: a launch of their own
     hipLaunchKernelGGL(rg_swing_ik_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, h->dcfg, h->st, dout, B);
     HIPCHK(h, hipGetLastError());
@@ -531,14 +534,14 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   if (pev) HIPCHK(h, hipEventRecord(pev[3], s));
   if (ring >= 0) HIPCHK(h, hipEventRecord(h->audit_fused[ring], s));
   if (direct_now) HIPCHK(h, hipStreamWaitEvent(s, h->direct_done, 0));   // the direct robots' actions are part of this tick
-  if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, s, head ? RETRY_AFTER_HEAD : (direct_now ? RETRY_LISTS : RETRY_ALL)));
-  else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, s, 0));
+  if (h->auto_retry && H == 10) HIPCHK(h, launch_qp_resolve_h10(h->mu4, h->dcfg, h->st, dout, B, h->cu_count, s, head ? RETRY_AFTER_HEAD : (direct_now ? RETRY_LISTS : RETRY_ALL)));
+  else if (h->auto_retry) HIPCHK(h, launch_qp_sched_retry_h20(h->mu4, h->dcfg, h->st, dout, B, h->cu_count, s, 0));
   if (pev) { HIPCHK(h, hipEventRecord(pev[5], s)); h->prof_n++; }
   if (ring >= 0) {
     // the same exact body, in audit mode, over the captured records: side stream, ordered after the ADMM launch only
     HIPCHK(h, hipStreamWaitEvent(h->audit_stream, h->audit_fused[ring], 0));
-    if (H == 10) HIPCHK(h, launch_qp_resolve_h10(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, RETRY_AUDIT));
-    else HIPCHK(h, launch_qp_sched_retry_h20(h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
+    if (H == 10) HIPCHK(h, launch_qp_resolve_h10(h->mu4, h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, RETRY_AUDIT));
+    else HIPCHK(h, launch_qp_sched_retry_h20(h->mu4, h->dcfg, h->st, dout, B, h->cu_count, h->audit_stream, 1));
     HIPCHK(h, hipEventRecord(h->audit_done[ring], h->audit_stream));
     h->audit_inflight[ring] = true;
   }

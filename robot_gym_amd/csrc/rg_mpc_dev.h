@@ -37,7 +37,8 @@
 struct DevCfg {
   int H, window, kin_mode, ik_iters, admm_iters;
   int accel_from;        // first ADMM iteration at which a vote may extrapolate the iterate along its dominant mode (0 = never)
-  double dt, mass, inv_mass, body_height, alpha, mu, fz_min, fz_max, g;
+  double dt, mass, inv_mass, body_height, alpha, mu, fz_min, fz_max, g;   // mu: the friction coefficient when all four legs share one
+  double mu4[4];         // per leg (FR, FL, RR, RL); the MU4 kernel instantiations read this (rg_mpc_create picks them when the four differ)
   double Iinv[9];
   double w[13];
   double stance_dur[4], duty[4], init_phase[4];
@@ -259,6 +260,14 @@ __device__ inline void leg_ik(const DevCfg *c, int leg, const double target[3], 
     }
   }
   qo[0] = q[0]; qo[1] = q[1]; qo[2] = q[2];
+}
+
+// Friction coefficient of a leg.  MU4 = false (the four coefficients are equal: every shipped robot, reference 0.45 x 4
+// [UPSTREAM-RECALL, SURVEY 8a-18]): one wave-uniform value that stays in SGPRs across the solver loops.  MU4 = true: the
+// leg's own, a per-lane value -- its own kernel instantiations, so that the uniform case pays no register for it.
+template <bool MU4>
+__device__ __forceinline__ double leg_mu(const DevCfg *__restrict__ c, const int leg) {
+  if constexpr (MU4) return c->mu4[leg & 3]; else return c->mu;
 }
 
 // Euclidean projection onto { |x| <= mu z, |y| <= mu z, lo <= z <= hi }.

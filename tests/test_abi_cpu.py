@@ -66,7 +66,7 @@ def test_create_rejects_bad_config_before_touching_the_gpu():
     # horizons: only 10 and 20 have compiled, GPU-tested solver bodies -- everything else must be refused here, never
     # accepted and then silently not solved (round-1 finding: horizons 11-19 could leave a stance-leg bin unlaunched)
     for bad in (dict(horizon=0), dict(horizon=21), dict(horizon=5), dict(horizon=12), dict(horizon=15), dict(horizon=16),
-                dict(mu=(0.45, 0.45, 0.4, 0.45)), dict(window=0), dict(kin_mode=2),
+                dict(mu=(0.45, 0.45, -0.4, 0.45)), dict(mu=(0.0, 0.45, 0.45, 0.45)), dict(window=0), dict(kin_mode=2),
                 dict(solver=7), dict(solver=4), dict(admm_rho34_scale=0.0), dict(admm_rho_sched_scale=-1.0), dict(audit_k=1 << 27), dict(admm_relax=2.5), dict(motor_dir=(0.5,) * 12), dict(inertia=(0.0,) * 9),
                 dict(solver=1, horizon=20), dict(solver=1, contact_lookahead=1, horizon=20), dict(contact_lookahead=1, horizon=12),
                 dict(reserved0=1), dict(reserved0=32), dict(reserved2=1), dict(reserved3=1), dict(reserved4=1), dict(lane_grid=3), dict(lane_grid=-1),

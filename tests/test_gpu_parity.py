@@ -830,3 +830,29 @@ def test_recall_sensitive_conventions_are_config_switches(oracle_lib, switch, ho
         assert diff == 0.0, diff
     else:
         assert diff > 1e-3, (switch, diff)   # the other reading gives other commands: the test above would notice a switch that is not wired
+
+
+@pytest.mark.parametrize("case", ["h10_hybrid", "h10_hybrid_wide", "h10_admm_exact_resolve", "h10_exact_everywhere", "h20_hybrid", "h20_admm", "h10_schedule", "h20_schedule"])
+def test_per_leg_friction_coefficients(oracle_lib, case):
+    """Unequal friction coefficients per leg (upstream's foot_friction_coeffs; the reference passes 0.45 x 4):
+    every plan's kernels with the coefficient carried per lane, against the oracle's per-block mu.  A low coefficient on one
+    leg makes its friction rows active: the commands must differ from the equal-coefficient ones."""
+    over = dict(h10_hybrid=dict(lane_grid=1), h10_hybrid_wide=dict(lane_grid=2), h10_admm_exact_resolve=dict(solver=2, admm_iters=60),
+                h10_exact_everywhere=dict(solver=1), h20_hybrid=dict(horizon=20), h20_admm=dict(horizon=20, solver=2),
+                h10_schedule=dict(contact_lookahead=1), h20_schedule=dict(horizon=20, contact_lookahead=1))[case]
+    mu = (0.3, 0.45, 0.6, 0.45)
+    cfg = MPCConfig.for_robot("ghost", mu=mu, **over)
+    state, cmd, t_off = synthetic.make_states(80, cfg, seed=61)
+    cmd = (cmd * np.float32(2.0)).astype(np.float32)   # harder commands: more robots on their friction limits
+    ticks = 8 if cfg.horizon == 20 else 14
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=ticks, jitter=0.1)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=ticks, jitter=0.1)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
+    same = helpers.run_oracle(oracle_lib, MPCConfig.for_robot("ghost", **over), state, cmd, t_off, ticks=ticks, jitter=0.1)
+    assert max(float(np.abs(a["grf"] - b["grf"]).max()) for a, b in zip(orc, same)) > 1.0   # (N) the coefficients matter on these inputs
+    # and no force leaves its own leg's pyramid
+    for o in gpu:
+        f = -o["grf"].astype(np.float64).reshape(-1, 4, 3)
+        lim = np.asarray(mu)[None, :] * f[:, :, 2]
+        assert (np.abs(f[:, :, 0]) <= lim + 1e-3).all() and (np.abs(f[:, :, 1]) <= lim + 1e-3).all()
