@@ -240,6 +240,15 @@ int rg_mpc_set_gait(rg_mpc_handle *h, const double *stance_duration, const doubl
 /* MPCController.get_action (mpc_controller.py:102-106) for all B robots at clock value t. */
 int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const rg_mpc_out_ptrs *out, void *stream);
 
+/* The same tick for a caller whose robot state lives on the HOST -- the drop-in plugin at batch 1 (the reference's
+ * MPCController.get_action gathers its state from PyBullet getters, mpc_controller.py:102-106) and a vectorised env:
+ * copies slab_bytes from host_slab (pinned memory: the caller's staging area for every input array) to dev_slab, runs
+ * rg_mpc_step on `in` / `out` (device pointers, normally into dev_slab), copies the [B][60] action slab to action_host
+ * (pinned) and WAITS for it: four stream operations and the synchronisation in one call across the ABI.  action_host may be
+ * NULL (no copy back, no wait). */
+int rg_mpc_step_host(rg_mpc_handle *h, double t, const void *host_slab, void *dev_slab, int64_t slab_bytes,
+                     const rg_mpc_state_ptrs *in, const rg_mpc_out_ptrs *out, float *action_host, void *stream);
+
 /* RobotMotorModel.convert_to_torque, HYBRID branch (model/robots/simple_motor.py:128-140):
  * action [B][60], q/qd [12][B] -> tau [B][12].  Device pointers. */
 int rg_mpc_hybrid_to_torque(rg_mpc_handle *h, const float *action, const float *q, const float *qd, float *tau, void *stream);

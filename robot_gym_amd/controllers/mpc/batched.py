@@ -160,6 +160,29 @@ class BatchedMPCController:
         self._handle.step(t, sp, self._out, self._stream())
         return self.action
 
+    def bind_host_state(self, packed: "PackedState", action_host):
+        """Prepare the host-resident fast path (get_action_host): validate ONCE that `packed` (a PackedState of this batch
+        on this device, pinned) and `action_host` (pinned float32 [B,60]) fit, and build the pointer structs the per-tick
+        call reuses -- the per-tick path then is one call across the C-ABI (rg_mpc_step_host)."""
+        if packed.dev_slab.device != self.device or tuple(packed.dev_slab.shape[1:]) != (self.batch,) or not packed.host_slab.is_pinned():
+            raise ValueError("bind_host_state: PackedState of another batch / device, or not pinned")
+        if action_host.dtype != torch.float32 or tuple(action_host.shape) != (self.batch, 60) or not action_host.is_pinned() or not action_host.is_contiguous():
+            raise ValueError(f"bind_host_state: action_host must be a pinned contiguous float32 [{self.batch},60] tensor")
+        sp = mpc_abi.CStatePtrs()
+        for name, comps, dt in STATE_FIELDS:
+            if name in ("foot_pos", "jac") and self.cfg.kin_mode == 1:
+                continue
+            setattr(sp, name, packed.dev[name].data_ptr())
+        self._host_bound = (sp, packed, action_host, packed.host_slab.data_ptr(), packed.dev_slab.data_ptr(),
+                            packed.host_slab.numel() * packed.host_slab.element_size(), action_host.data_ptr())
+
+    def get_action_host(self, t):
+        """One tick from the bound host slab: upload, step, download, wait (rg_mpc_step_host).  Returns the bound pinned
+        action tensor (overwritten by the next call)."""
+        sp, packed, action_host, hptr, dptr, nbytes, aptr = self._host_bound
+        self._handle.step_host(t, hptr, dptr, nbytes, sp, self._out, aptr, self._stream())
+        return action_host
+
     def set_gait(self, stance_duration=None, duty_factor=None, init_phase=None, init_state=None):
         """Per-robot gait timing, [4,B] each (float64; init_state int32, optional): the OpenloopGaitGenerator arguments of
         reference mpc_controller.py:30-35, one row per robot.  All None returns to the config-wide gait.  Call before reset()."""

@@ -58,6 +58,8 @@ class MPCController(Controller):
         self._state = PackedState(1, self._dev)     # one pinned slab: one H2D copy per tick instead of eight
         self._host = {n: t.numpy() for n, t in self._state.host.items()}
         self._act_host = torch.zeros(1, 60, dtype=torch.float32, pin_memory=True)
+        self._batched.bind_host_state(self._state, self._act_host)   # per tick: one call across the C-ABI (rg_mpc_step_host)
+        self._act_np = self._act_host[0].numpy()
         self.update_controller_params((0.0, 0.0, 0.0))
 
     @property
@@ -87,13 +89,11 @@ class MPCController(Controller):
         h["foot_pos"][:, 0] = np.asarray(rb.GetFootPositionsInBaseFrame(), dtype=np.float32).reshape(12)
         h["jac"][:, 0] = np.stack([self._kinematics.leg_jacobian(leg) for leg in range(4)]).reshape(36)
         h["contact"][:, 0] = np.asarray(rb.GetFootContacts(), dtype=np.int32)
-        return self._state.upload()
 
     def get_action(self):
-        act = self._batched.get_action(self.get_time_since_reset(), self._gather_state())
-        self._act_host.copy_(act, non_blocking=True)
-        torch.cuda.current_stream(self._dev).synchronize()
-        return self._act_host[0].numpy().copy()
+        self._gather_state()                                             # the robot's getters into the pinned slab
+        self._batched.get_action_host(self.get_time_since_reset())       # upload, the tick's launches, download, wait
+        return self._act_np.copy()
 
     def reset(self):
         self._batched.reset(None, t0=self.get_time_since_reset())

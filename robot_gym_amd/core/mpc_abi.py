@@ -52,7 +52,7 @@ class COutPtrs(C.Structure):
     _fields_ = [(n, fp) for n in ("action", "grf", "tau_stance", "leg_state", "desired_state", "phase", "foot_target", "v_body")]
 
 
-EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_set_gait", "rg_mpc_step", "rg_mpc_hybrid_to_torque",
+EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_set_gait", "rg_mpc_step", "rg_mpc_step_host", "rg_mpc_hybrid_to_torque",
            "rg_mpc_hybrid_to_torque_substeps",
            "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_audit_stats", "rg_mpc_last_direct_count", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
@@ -80,6 +80,8 @@ def load_library(path=None):
     L.rg_mpc_set_command.restype = i32
     L.rg_mpc_step.argtypes = [fp, d, C.POINTER(CStatePtrs), C.POINTER(COutPtrs), fp]
     L.rg_mpc_step.restype = i32
+    L.rg_mpc_step_host.argtypes = [fp, d, fp, fp, C.c_int64, C.POINTER(CStatePtrs), C.POINTER(COutPtrs), fp, fp]
+    L.rg_mpc_step_host.restype = i32
     L.rg_mpc_hybrid_to_torque.argtypes = [fp, fp, fp, fp, fp, fp]
     L.rg_mpc_hybrid_to_torque.restype = i32
     L.rg_mpc_hybrid_to_torque_substeps.argtypes = [fp, fp, fp, fp, fp, i32, fp]
@@ -179,6 +181,10 @@ class MpcHandle:
 
     def step(self, t, state_ptrs: CStatePtrs, out_ptrs: COutPtrs, stream=None):
         self._check(self._lib.rg_mpc_step(self._h, float(t), C.byref(state_ptrs), C.byref(out_ptrs), stream))
+
+    def step_host(self, t, host_slab_ptr, dev_slab_ptr, slab_bytes, state_ptrs: CStatePtrs, out_ptrs: COutPtrs, action_host_ptr, stream=None):
+        """rg_mpc_step_host: upload the pinned state slab, step, download the action slab and wait -- one call across the ABI."""
+        self._check(self._lib.rg_mpc_step_host(self._h, float(t), host_slab_ptr, dev_slab_ptr, int(slab_bytes), C.byref(state_ptrs), C.byref(out_ptrs), action_host_ptr, stream))
 
     def set_gait(self, stance_ptr, duty_ptr, phase_ptr, init_state_ptr=None, stream=None):
         self._check(self._lib.rg_mpc_set_gait(self._h, stance_ptr, duty_ptr, phase_ptr, init_state_ptr, stream))

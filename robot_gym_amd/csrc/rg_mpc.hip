@@ -548,6 +548,24 @@ int rg_mpc_step(rg_mpc_handle *h, double t, const rg_mpc_state_ptrs *in, const r
   return RG_MPC_OK;
 }
 
+int rg_mpc_step_host(rg_mpc_handle *h, double t, const void *host_slab, void *dev_slab, int64_t slab_bytes,
+                     const rg_mpc_state_ptrs *in, const rg_mpc_out_ptrs *out, float *action_host, void *stream) {
+  if (!h || !host_slab || !dev_slab || slab_bytes <= 0 || !in || !out) { if (h) h->err = "step_host: null argument"; return RG_MPC_ERR_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
+    HIPCHK(h, hipMemcpyAsync(dev_slab, host_slab, (size_t)slab_bytes, hipMemcpyHostToDevice, s));
+  }
+  const int rc = rg_mpc_step(h, t, in, out, stream);
+  if (rc) return rc;
+  if (action_host) {
+    DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
+    HIPCHK(h, hipMemcpyAsync(action_host, out->action, sizeof(float) * 60 * (size_t)h->B, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+  }
+  return RG_MPC_OK;
+}
+
 int rg_mpc_profile_begin(rg_mpc_handle *h, int32_t max_steps) {
   if (!h || max_steps < 1 || max_steps > 100000) { if (h) h->err = "profile_begin: bad max_steps"; return RG_MPC_ERR_INVALID; }
   DeviceScope dev_(h->device); HIPCHK(h, dev_.err);
