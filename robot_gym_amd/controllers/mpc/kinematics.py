@@ -97,6 +97,20 @@ class PybulletKinematics:
             raise ValueError("translational Jacobian must have 3 rows")
         return jv[:, 6 + 3 * leg_id: 9 + 3 * leg_id]
 
+    def all_leg_jacobians(self, out):
+        """The four legs' 3 x 3 blocks into out[4, 3, 3] with ONE read of the joint states (the per-tick state gather of the
+        drop-in controller: the reference asks per leg and per call, controllers/mpc/kinematics.py:13-30)."""
+        rb = self._robot
+        angles = [s[0] for s in rb.GetJointStates]
+        zeros = [0] * len(angles)
+        bullet, rid, links = rb.pybullet_client, rb.GetRobotId, rb.GetFootLinkIds
+        for leg_id in range(4):
+            jv, _ = bullet.calculateJacobian(rid, links[leg_id], (0, 0, 0), angles, zeros, zeros)
+            if len(jv) != 3:
+                raise ValueError("translational Jacobian must have 3 rows")
+            for i in range(3):
+                out[leg_id, i] = jv[i][6 + 3 * leg_id: 9 + 3 * leg_id]
+
     def MapContactForceToJointTorques(self, leg_id, contact_force):
         J = self.leg_jacobian(leg_id)
         direction = np.asarray(self._robot.GetMotorConstants().MOTOR_DIRECTION, dtype=np.float64)

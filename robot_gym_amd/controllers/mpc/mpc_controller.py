@@ -60,6 +60,9 @@ class MPCController(Controller):
         self._act_host = torch.zeros(1, 60, dtype=torch.float32, pin_memory=True)
         self._batched.bind_host_state(self._state, self._act_host)   # per tick: one call across the C-ABI (rg_mpc_step_host)
         self._act_np = self._act_host[0].numpy()
+        # column views of the one robot's slab entries, made once (batch 1: every field's column is contiguous)
+        self._col = {n: a[:, 0] for n, a in self._host.items()}
+        self._jac_view = self._host["jac"][:, 0].reshape(4, 3, 3)
         self.update_controller_params((0.0, 0.0, 0.0))
 
     @property
@@ -80,15 +83,15 @@ class MPCController(Controller):
         self._batched.update_controller_params(torch.tensor([list(map(float, params))], dtype=torch.float32))
 
     def _gather_state(self):
-        rb, h = self._robot, self._host
-        h["rpy"][:, 0] = rb.GetBaseRollPitchYaw()
-        h["rpy_rate"][:, 0] = rb.GetBaseRollPitchYawRate()
-        h["v_world"][:, 0] = rb.GetBaseVelocity()
-        h["quat"][:, 0] = rb.GetTrueBaseOrientation()
-        h["q"][:, 0] = rb.GetMotorAngles()
-        h["foot_pos"][:, 0] = np.asarray(rb.GetFootPositionsInBaseFrame(), dtype=np.float32).reshape(12)
-        h["jac"][:, 0] = np.stack([self._kinematics.leg_jacobian(leg) for leg in range(4)]).reshape(36)
-        h["contact"][:, 0] = np.asarray(rb.GetFootContacts(), dtype=np.int32)
+        rb, c = self._robot, self._col
+        c["rpy"][:] = rb.GetBaseRollPitchYaw()
+        c["rpy_rate"][:] = rb.GetBaseRollPitchYawRate()
+        c["v_world"][:] = rb.GetBaseVelocity()
+        c["quat"][:] = rb.GetTrueBaseOrientation()
+        c["q"][:] = rb.GetMotorAngles()
+        c["foot_pos"][:] = np.asarray(rb.GetFootPositionsInBaseFrame(), dtype=np.float32).reshape(12)
+        self._kinematics.all_leg_jacobians(self._jac_view)
+        c["contact"][:] = rb.GetFootContacts()
 
     def get_action(self):
         self._gather_state()                                             # the robot's getters into the pinned slab

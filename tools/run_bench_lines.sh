@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun) AFTER profiles/ holds the summaries of the current kernel sources: the bench line of every
 # BASELINE workload, now carrying the profile-derived fields (roofline.traffic, roofline.issue_view).  -> gpurun_out/bench_<key>.json
 set -u
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 run() { local key=$1; shift; python3 bench.py --steps 20 --warmup 5 "$@" > gpurun_out/bench_$key.json 2> gpurun_out/bench_$key.err; echo "$key: $(python3 -c "import json;d=json.loads(open('gpurun_out/bench_$key.json').read());print(round(d['value']/1e6,3),'M steps/s', d['roofline']['kernel_ms'], 'traffic', d['roofline']['traffic'])")"; }
