@@ -702,7 +702,7 @@ def main():
             clocks = []
             el_su, _, _, _, ctl = run(slabs, nticks, 20, False, clock_probe=clocks)
             sustained = {"steps_per_s": B * nticks / el_su, "seconds": round(el_su, 2), "ticks": nticks,
-                         "vs_value_pct": None, "sclk_mhz": clocks or None}
+                         "vs_value_pct": None, "sclk_mhz_sysfs": clocks or None}   # (the `*` level of pp_dpm_sclk at three instants: what sysfs shows this user, not a clock trace)
         if B == 1:
             try:
                 dropin_us = dropin_latency(cfg)
@@ -742,6 +742,9 @@ def main():
             wkey = "kin0chain" if wkey == "headline" else f"{wkey}_kin0chain"
         if args.random_schedule and args.cap is not None:
             wkey = f"config5_cap{args.cap}"
+        if args.lane_grid:
+            wl += f", lane grid {args.lane_grid} ({'one wave' if args.lane_grid == 1 else '256 lanes'} per robot)"
+            wkey = f"grid{args.lane_grid}" if wkey == "headline" else f"{wkey}_grid{args.lane_grid}"
         if args.solver is not None and args.solver != MPCConfig.for_robot(args.robot).solver:   # another solver plan than the default: its own profile key
             wl += f", solver plan {args.solver}"
             wkey = f"s{args.solver}" if wkey == "headline" else f"{wkey}_s{args.solver}"

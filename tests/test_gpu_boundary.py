@@ -307,7 +307,20 @@ def test_introspection_views_agree():
     dev = {n: torch.from_numpy(np.ascontiguousarray(state[n])).cuda() for n in ("rpy", "rpy_rate", "v_world", "quat", "q", "foot_pos", "jac")}
     dev["contact"] = torch.from_numpy(contact).cuda()
     assert np.array_equal(ctl2.get_action(0.03, dev).cpu().numpy(), act_packed)
-    ctl.close(); ctl2.close()
+    # and through rg_mpc_step_host (upload, step, download and wait in one call across the ABI): identical again
+    ctl3 = BatchedMPCController(B, cfg)
+    ctl3.reset_at(-t_off)
+    ctl3.update_controller_params(torch.from_numpy(cmd.T.copy()))
+    ps3 = PackedState(B, ctl3.device)
+    ps3.host_slab.copy_(ps.host_slab)
+    act_host = torch.zeros(B, 60, dtype=torch.float32, pin_memory=True)
+    ctl3.bind_host_state(ps3, act_host)
+    assert ctl3.get_action_host(0.03) is act_host and np.array_equal(act_host.numpy(), act_packed)
+    with pytest.raises(ValueError):
+        ctl3.bind_host_state(ps3, torch.zeros(B, 60))                     # not pinned
+    with pytest.raises(ValueError):
+        ctl3.bind_host_state(PackedState(B + 1, ctl3.device), act_host)   # another batch
+    ctl.close(); ctl2.close(); ctl3.close()
 
 
 def test_non_finite_state_is_counted_and_contained(oracle_lib):

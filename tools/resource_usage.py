@@ -33,4 +33,4 @@ print(out)
 if len(sys.argv) > 1:
     sys.path.insert(0, ROOT)
     import bench
-    open(sys.argv[1], "w").write(f"# hipcc -Rpass-analysis=kernel-resource-usage (tools/resource_usage.py), kernel sources {bench.source_hash()}\n" + out + "\n")
+    open(sys.argv[1], "w").write(f"# hipcc -Rpass-analysis=kernel-resource-usage (tools/resource_usage.py), {bench.evidence_header()}\n" + out + "\n")

@@ -5,17 +5,14 @@ set -u
 TAG=${TAG:-r5}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
+python3 tools/evidence_guard.py || exit 1
 run() { local key=$1; shift; python3 bench.py --steps 20 --warmup 5 "$@" > gpurun_out/bench_$key.json 2> gpurun_out/bench_$key.err; echo "$key: $(python3 -c "import json;d=json.loads(open('gpurun_out/bench_$key.json').read());print(round(d['value']/1e6,3),'M steps/s', d['roofline']['kernel_ms'], 'traffic', d['roofline']['traffic'])")"; }
 run headline
 run config2 --batch 1024 --fixed-cmd
 run b1 --batch 1
 run h20 --horizon 20
 run config5 --horizon 20 --random-schedule
-run config5_cap600 --horizon 20 --random-schedule --cap 600
 run b32768 --batch 32768
 run kin1 --kin-mode 1
-# the geometry kin_mode 1 computes on the device (chain forward kinematics of the synthetic joint angles) handed to kin_mode 0
-# as inputs: the same QPs as the kin1 line, so the difference between the two is the cost of the on-device kinematics
-tools/collect_profiles.sh ${TAG}_kin0chain stats --chain-geometry > gpurun_out/collect_kin0chain.log 2>&1
-run kin0chain --chain-geometry
+run config2_grid1 --batch 1024 --fixed-cmd --lane-grid 1
 python3 tools/vec_env_bench.py 20 > gpurun_out/${TAG}_vec_env_host.txt 2> gpurun_out/${TAG}_vec_env_host.err; cat gpurun_out/${TAG}_vec_env_host.txt
