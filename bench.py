@@ -339,14 +339,32 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
     return out
 
 
-def gpu_sclk_mhz():
-    """Current shader clock of the first GPU in MHz from sysfs (the active `*` line of pp_dpm_sclk), or None when the box does
-    not expose it to this user."""
+def gpu_sclk_mhz(device_index=0):
+    """Current shader clock in MHz of THE GPU this process computes on, from sysfs, or None when the box does not expose it.
+    A multi-GPU host shows every card under /sys/class/drm whatever the container may use, so the card is picked by the HIP
+    device's PCI address; then hwmon's freq1_input (the current frequency), else the active `*` level of pp_dpm_sclk."""
     import glob
     import re
-    for path in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+    except Exception:
+        pass
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    if want is not None:
+        match = [c for c in cards if os.path.basename(os.path.realpath(c)).lower().startswith(want)]
+        if not match:
+            return None
+        cards = match
+    for dev in cards:
+        for path in sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*", "freq1_input"))):
+            try:
+                return int(int(open(path).read().strip()) / 1e6)
+            except (OSError, ValueError):
+                pass
         try:
-            for line in open(path):
+            for line in open(os.path.join(dev, "pp_dpm_sclk")):
                 if line.rstrip().endswith("*"):
                     m = re.search(r"(\d+)\s*[Mm][Hh]z", line)
                     if m:
@@ -602,7 +620,7 @@ def main():
         for k in range(steps):
             one_step(warmup + k)
             if clock_probe is not None and k in (steps // 100, steps // 2, steps - 1):   # (the host runs ahead of the GPU by its queue depth only)
-                clock_probe.append(gpu_sclk_mhz())
+                clock_probe.append(gpu_sclk_mhz(device.index if device.type == "cuda" else 0))
         sync()
         if dist is not None:
             dist.barrier()
@@ -702,7 +720,7 @@ def main():
             clocks = []
             el_su, _, _, _, ctl = run(slabs, nticks, 20, False, clock_probe=clocks)
             sustained = {"steps_per_s": B * nticks / el_su, "seconds": round(el_su, 2), "ticks": nticks,
-                         "vs_value_pct": None, "sclk_mhz_sysfs": clocks or None}   # (the `*` level of pp_dpm_sclk at three instants: what sysfs shows this user, not a clock trace)
+                         "vs_value_pct": None, "sclk_mhz_sysfs": clocks or None}   # (this GPU's sysfs shader clock at three instants of the run: hwmon freq1_input, else the active pp_dpm_sclk level; not a clock trace)
         if B == 1:
             try:
                 dropin_us = dropin_latency(cfg)

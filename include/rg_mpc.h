@@ -57,8 +57,9 @@ enum { RG_LEG_SWING = 0, RG_LEG_STANCE = 1, RG_LEG_EARLY_CONTACT = 2, RG_LEG_LOS
  *   online active-set method; mpc_controller.py:47-56 passes no solver) -- for the robots where it is also the cheaper way:
  *   one and two stance legs (every robot of a trot, 60 variables, one or two active constraints at the optimum) are solved
  *   by a one-wave dual active-set body warm-started from the robot's working set of the previous tick (warm_start); three
- *   and four legs keep the wrench-space ADMM with the exact re-solve behind it, as under RG_SOLVER_AUTO.  At horizon 20 and
- *   with contact_lookahead it is RG_SOLVER_AUTO. */
+ *   and four legs keep the wrench-space ADMM with the exact re-solve behind it, as under RG_SOLVER_AUTO.  At horizon 20 the
+ *   same split (the exact body on 256 lanes, the solve on one wave of them; three and four legs on the schedule body with a
+ *   constant schedule).  With contact_lookahead it is RG_SOLVER_AUTO. */
 enum { RG_SOLVER_ADMM = 0, RG_SOLVER_ACTIVE_SET = 1, RG_SOLVER_AUTO = 2, RG_SOLVER_HYBRID = 3 };
 
 /* Everything MPCController._setup_controller wires (mpc_controller.py:28-66) plus the
@@ -317,6 +318,11 @@ int rg_mpc_debug_poison_lds(rg_mpc_handle *h, void *stream);
 /* Comma-separated labels of the six avg_ms windows for this handle's launch plan (horizon 10 with the
  * ADMM solver uses one fused QP launch: {front, fused QP, exact re-solves, -, -, whole step}). */
 const char *rg_mpc_profile_window_names(const rg_mpc_handle *h);
+
+/* What rg_mpc_create chose for this handle, as one line of space-separated key=value pairs (keys: solver, horizon, batch,
+ * lanes -- lanes per robot in the QP launch: 64 or 256, see lane_grid --, exact12 -- one / two stance legs on the exact body --,
+ * mu -- "uniform" or "per_leg" kernel instantiations --, schedule, audit, direct).  For logs and tests; valid until destroy. */
+const char *rg_mpc_plan_description(const rg_mpc_handle *h);
 
 /* Names of the kernels launched by rg_mpc_step, for matching rocprof rows. */
 const char *rg_mpc_kernel_names(void);

@@ -179,6 +179,8 @@ class BatchedMPCController:
     def get_action_host(self, t):
         """One tick from the bound host slab: upload, step, download, wait (rg_mpc_step_host).  Returns the bound pinned
         action tensor (overwritten by the next call)."""
+        if getattr(self, "_host_bound", None) is None:
+            raise RuntimeError("get_action_host: call bind_host_state(packed_state, pinned_action) first")
         sp, packed, action_host, hptr, dptr, nbytes, aptr = self._host_bound
         self._handle.step_host(t, hptr, dptr, nbytes, sp, self._out, aptr, self._stream())
         return action_host

@@ -54,7 +54,7 @@ class COutPtrs(C.Structure):
 
 EXPORTS = ("rg_mpc_create", "rg_mpc_reset", "rg_mpc_reset_at", "rg_mpc_set_command", "rg_mpc_set_gait", "rg_mpc_step", "rg_mpc_step_host", "rg_mpc_hybrid_to_torque",
            "rg_mpc_hybrid_to_torque_substeps",
-           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_audit_stats", "rg_mpc_last_direct_count", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
+           "rg_mpc_last_bin_counts", "rg_mpc_last_solver_stats", "rg_mpc_last_iterations", "rg_mpc_audit_stats", "rg_mpc_last_direct_count", "rg_mpc_profile_begin", "rg_mpc_profile_stride", "rg_mpc_profile_end", "rg_mpc_kernel_names", "rg_mpc_plan_description", "rg_mpc_profile_window_names", "rg_mpc_debug_poison_lds", "rg_mpc_destroy", "rg_mpc_last_error",
            "rg_mpc_abi_version", "rg_mpc_config_size")
 
 _lib = None
@@ -102,6 +102,8 @@ def load_library(path=None):
     L.rg_mpc_profile_end.argtypes = [fp, C.POINTER(C.c_float * 6), C.POINTER(i32 * 5), fp]
     L.rg_mpc_profile_end.restype = i32
     L.rg_mpc_kernel_names.restype = C.c_char_p
+    L.rg_mpc_plan_description.argtypes = [C.c_void_p]
+    L.rg_mpc_plan_description.restype = C.c_char_p
     L.rg_mpc_last_iterations.argtypes = [fp, C.POINTER(i32), C.POINTER(i32), fp]
     L.rg_mpc_last_iterations.restype = i32
     L.rg_mpc_profile_stride.argtypes = [fp, i32]
@@ -249,6 +251,10 @@ class MpcHandle:
 
     def profile_window_names(self):
         return self._lib.rg_mpc_profile_window_names(self._h).decode().split(",")
+
+    def plan(self):
+        """rg_mpc_plan_description as a dict: what create chose (solver, horizon, batch, lanes, exact12, mu, schedule, audit, direct)."""
+        return dict(kv.split("=", 1) for kv in self._lib.rg_mpc_plan_description(self._h).decode().split())
 
     def kernel_names(self):
         return self._lib.rg_mpc_kernel_names().decode().split(",")

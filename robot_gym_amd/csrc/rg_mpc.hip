@@ -3,15 +3,17 @@
 // Path: one control tick of robot-gym's MPCController.get_action()
 // (reference robot_gym/controllers/mpc/mpc_controller.py:102-106) for B robots.  Launch plan per tick:
 //   rg_front_kernel            one lane per (robot, leg), coalesced SoA reads: gait phase, CoM velocity filter,
-//                              Raibert swing foothold + trajectory + IK, the stance-QP record, and the work lists
+//                              Raibert swing foothold + trajectory, the stance-QP record, and the work lists
 //                              (cost classes predicted from each robot's previous-tick iteration count).
-//   rg_qp_fused_kernel<H>      one workgroup per robot (one wave at H = 10, 256 lanes at H = 20), every stance-leg
-//                              count in one launch: closed-form Kronecker QP assembly, in-register symmetric sweep
-//                              inverse, over-relaxed friction-pyramid ADMM (force space for 1-2 legs, wrench space
-//                              for 3-4 legs and for contact schedules), J' f, 60-float action row.
-//                              RG_SOLVER_HYBRID (default, horizon 10): one- and two-leg robots are solved EXACTLY in this
-//                              launch by a one-wave dual active-set body warm-started from the robot's previous working set
-//                              (rg_qp_exact_kernel.inc); three and four legs keep the wrench-space ADMM body.
+//   rg_qp_fused_kernel<H, ..>  one workgroup per robot (one wave at H = 10 -- 256 lanes for small batches, rg_mpc_config.lane_grid --,
+//                              256 lanes at H = 20), every stance-leg count in one launch: closed-form Kronecker QP assembly,
+//                              in-register symmetric sweep inverse, over-relaxed friction-pyramid ADMM (force space for 1-2
+//                              legs, wrench space for 3-4 legs and for contact schedules), J' f, 60-float action row; the
+//                              swing-leg IK lanes ride along as the grid's last workgroups.
+//                              RG_SOLVER_HYBRID (default; horizons 10 and 20): one- and two-leg robots are solved EXACTLY in
+//                              this launch by a dual active-set body warm-started from the robot's previous working set
+//                              (rg_qp_exact_kernel.inc: one wave does the solve, on 256-lane grids the other three serve its
+//                              mat-vecs); three and four legs keep the wrench-space ADMM body (H = 20: the schedule body).
 //   rg_qp_resolve_kernel / rg_qp_sched_retry_kernel
 //                              exact dual active-set re-solve (one body per kernel) of the robots the launch above could
 //                              not finish: ADMM at its iteration cap, an exact working set that overflowed.  The same
@@ -92,6 +94,7 @@ struct rg_mpc_handle {
   int cu_count = 256;
   std::vector<void *> allocs;
   std::string err;
+  std::string plan;                 // rg_mpc_plan_description
   // optional per-kernel event timing
   std::vector<hipEvent_t> ev;   // RG_PROF_EV events per profiled step
   int prof_max = 0, prof_n = 0, prof_stride = 1;   // events are recorded on every prof_stride-th step
@@ -301,6 +304,8 @@ int rg_mpc_abi_version(void) { return RG_MPC_ABI_VERSION; }
 int rg_mpc_config_size(void) { return (int)sizeof(rg_mpc_config); }
 const char *rg_mpc_kernel_names(void) { return "rg_front_kernel,rg_qp_fused_kernel,rg_qp_resolve_kernel,rg_qp_sched_kernel,rg_qp_sched_retry_kernel,rg_swing_ik_kernel,rg_hybrid_to_torque_kernel,rg_reset_kernel"; }
 
+const char *rg_mpc_plan_description(const rg_mpc_handle *h) { return h ? h->plan.c_str() : ""; }
+
 const char *rg_mpc_last_error(const rg_mpc_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mpc_handle **out) {
@@ -325,8 +330,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
             (cfg->lane_grid == 2 || (cfg->lane_grid == 0 && batch <= RG_MPC_WIDE_BATCH));
   h->fused = !(as_only && cfg->contact_lookahead);
   h->auto_retry = cfg->solver != RG_SOLVER_ADMM;
-  // exact re-solve body behind every robot the QP launch hands on: horizon 10 -- the four-leg force-space active-set body
-  // with absent (step, leg) blocks taken out (any stance-leg count, any schedule); horizon 20 -- the wrench-space one
+  // exact re-solve bodies behind every robot the QP launch hands on: horizon 10 -- one-wave bodies (force-space exact body
+  // for one / two legs, the schedule QP's wrench-space active-set body for the rest); horizon 20 -- the 256-lane wrench-space one
   h->retry_max_nc = h->auto_retry ? 4 : 0;
   int rc = build_devcfg(cfg, &h->hcfg, h->err);
   h->hcfg.plan = h->fused ? 1 : 0;
@@ -381,6 +386,14 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   }
 #undef CR
 #undef AL
+  {
+    static const char *solver_name[] = {"admm", "active_set", "auto", "hybrid"};
+    char buf[256];
+    const int lanes = (cfg->horizon == 20 || h->wide) ? 256 : 64;
+    snprintf(buf, sizeof(buf), "solver=%s horizon=%d batch=%d lanes=%d exact12=%d mu=%s schedule=%d audit=%d direct=%d", solver_name[cfg->solver], cfg->horizon, batch, lanes,
+             h->exact12 ? 1 : 0, h->mu4 ? "per_leg" : "uniform", cfg->contact_lookahead ? 1 : 0, h->audit_on ? 1 : 0, h->direct_on ? 1 : 0);
+    h->plan = buf;
+  }
   *out = h;
   int r = rg_mpc_reset(h, nullptr, batch, 0.0, nullptr);
   if (r) { g_create_err = h->err; rg_mpc_destroy(h); *out = nullptr; return r; }

@@ -517,3 +517,23 @@ def test_vec_env_with_device_kinematics(oracle_lib):
         assert m["tau_rel_max"] <= 1e-4 and m["q_abs"] <= 1e-5, (k, m)
     assert calls == []
     venv.close()
+
+
+def test_create_chooses_the_plan_from_config_and_batch():
+    """rg_mpc_plan_description: the lane grid follows the batch (256 lanes per robot up to RG_MPC_WIDE_BATCH = 1024 robots under
+    the default plan at horizon 10, one wave above; lane_grid forces either), the exact body serves one / two legs under the
+    hybrid plan at both horizons, unequal friction coefficients pick the per-leg instantiations."""
+    from robot_gym_amd.core.mpc_abi import MpcHandle
+    def plan(batch, **over):
+        h = MpcHandle(MPCConfig.for_robot("ghost", **{"lane_grid": 0, **over}), batch)   # (0 = the library's own choice, whatever --lane-grid the suite runs with)
+        p = h.plan()
+        h.close()
+        return p
+    assert plan(1)["lanes"] == "256" and plan(1024)["lanes"] == "256" and plan(1025)["lanes"] == "64" and plan(4096)["lanes"] == "64"
+    assert plan(4096, lane_grid=2)["lanes"] == "256" and plan(64, lane_grid=1)["lanes"] == "64"
+    assert plan(64, solver=2)["lanes"] == "64" and plan(64, contact_lookahead=1)["lanes"] == "64"      # the 256-lane grid is the default plan's
+    p20 = plan(512, horizon=20)
+    assert p20["lanes"] == "256" and p20["exact12"] == "1" and p20["solver"] == "hybrid" and p20["direct"] == "0"
+    assert plan(512, horizon=20, contact_lookahead=1)["exact12"] == "0" and plan(512, horizon=20, solver=2)["exact12"] == "0"
+    assert plan(8)["mu"] == "uniform" and plan(8, mu=(0.3, 0.45, 0.6, 0.45))["mu"] == "per_leg"
+    assert plan(8, audit_k=0)["audit"] == "0" and plan(8)["audit"] == "1" and plan(8, solver=1)["audit"] == "0"
