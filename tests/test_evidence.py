@@ -72,3 +72,31 @@ def test_round_evidence_names_a_commit_whose_sources_it_hashes():
     for csv in glob.glob(os.path.join(PROFILES, f"{ROUND}*_kernel_stats.csv")) + glob.glob(os.path.join(PROFILES, f"{ROUND}*_pmc_per_launch.csv")):
         tag = os.path.basename(csv).replace("_kernel_stats.csv", "").replace("_pmc_per_launch.csv", "")
         assert os.path.exists(os.path.join(PROFILES, f"{tag}_traffic.json")), f"{os.path.basename(csv)} has no {tag}_traffic.json naming its commit"
+
+
+def test_evidence_header_and_stamp_fallback(tmp_path, monkeypatch):
+    """bench.git_head(): the commit from git where there is a history; on the GPU box (no .git) from the stamp file
+    tools/stamp_commit.py wrote -- honoured only while its source hash is the tree's."""
+    if _git("rev-parse", "HEAD").returncode != 0:
+        pytest.skip("no git history here")
+    head = _git("rev-parse", "HEAD").stdout.strip()
+    commit, dirty = bench.git_head()
+    assert commit == head and dirty in (False, True)
+    hdr = bench.evidence_header()
+    assert hdr.startswith(f"kernel sources {bench.source_hash()} commit {head}")
+    # the fallback: pretend there is no git, with a valid and then a stale stamp
+    import subprocess
+    real_run = subprocess.run
+
+    def no_git(cmd, *a, **k):
+        if cmd and cmd[0] == "git":
+            raise OSError("no git here")
+        return real_run(cmd, *a, **k)
+    monkeypatch.setattr(subprocess, "run", no_git)
+    stamp = tmp_path / "stamp.json"
+    monkeypatch.setattr(bench, "STAMP_FILE", str(stamp))
+    assert bench.git_head() == (None, None)
+    json.dump({"commit": "ab" * 20, "dirty": False, "source_hash": bench.source_hash()}, open(stamp, "w"))
+    assert bench.git_head() == ("ab" * 20, False)
+    json.dump({"commit": "ab" * 20, "dirty": False, "source_hash": "0" * 16}, open(stamp, "w"))
+    assert bench.git_head() == (None, None)
