@@ -474,7 +474,10 @@ def _sweep_case(seed):
     return cfg, B, over, dict(state=state, cmd=cmd, t_off=t_off, ticks=5, jitter=0.1, gait=gait, sched_fn=sched_fn)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RG_SWEEP_SEEDS", "100"))))
+_SWEEP_OFFSET = int(os.environ.get("RG_SWEEP_OFFSET", "0"))   # RG_SWEEP_SEEDS seeds starting here (evidence runs cover disjoint ranges)
+
+
+@pytest.mark.parametrize("seed", range(_SWEEP_OFFSET, _SWEEP_OFFSET + int(os.environ.get("RG_SWEEP_SEEDS", "100"))))
 def test_randomised_configurations(oracle_lib, seed):
     """Seeded sweep over the configuration space (see _sweep_case).  Everything must match the oracle with no failures."""
     cfg, B, over, kw = _sweep_case(seed)
