@@ -237,6 +237,77 @@ def test_exact_body_overflow_goes_to_the_resolve_launch(oracle_lib):
     print("exact re-solves per tick:", [g["solver_stats"]["retried_exact"] for g in gpu], "largest two-leg work", gpu[-1]["iters"][two].max())
 
 
+def _hard_states(cfg, B, seed):
+    """Every other robot crouched (+0.15 m feet), tilted (roll / pitch 0.5 rad) and sliding (5 m/s): far more active
+    constraints than a walking robot has."""
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=seed)
+    fp = state["foot_pos"].reshape(4, 3, B).copy()
+    fp[:, 2, ::2] += 0.15
+    state["foot_pos"] = fp.reshape(12, B).astype(np.float32)
+    vw = state["v_world"].copy()
+    vw[0, ::2], vw[1, ::2] = 5.0, -5.0
+    state["v_world"] = vw
+    rpy = state["rpy"].copy()
+    rpy[0, ::2], rpy[1, ::2] = 0.5, -0.5
+    state["rpy"] = rpy
+    state["quat"] = synthetic._quat_from_rpy(rpy[0].astype(np.float64), rpy[1].astype(np.float64), rpy[2].astype(np.float64)).astype(np.float32)
+    return state, cmd, t_off
+
+
+def _take(state, cmd, t_off, idx):
+    B = t_off.shape[0]
+    sub = {k: (v[..., idx].copy() if isinstance(v, np.ndarray) and v.shape[-1] == B else v) for k, v in state.items()}
+    return sub, cmd[:, idx].copy(), t_off[idx].copy()
+
+
+def _torque_err(og, oo):
+    B = og["action"].shape[0]
+    tg, to = og["action"].astype(np.float64).reshape(B, 12, 5)[:, :, 4], oo["action"].astype(np.float64).reshape(B, 12, 5)[:, :, 4]
+    return (np.abs(tg - to) / np.maximum(np.abs(to), 1.0)).max(1)
+
+
+def test_horizon_20_exact_body_overflow_goes_to_the_retry_launch(oracle_lib):
+    """Horizon 20 under the default plan, on the crouched, tilted, sliding robots of the test above.
+    (1) Two-leg robots (120 variables) whose working set outgrows the 256-lane exact body's 64 slots are handed to the
+    horizon-20 re-solve launch, whose room (120) a two-leg QP cannot outgrow: exact, nobody fails, also with mu = 0.2.  Under
+    HYBRID no two-leg robot runs ADMM, so every re-solve counted on the two-leg-only batch IS such a hand-over.
+    (2) The whole batch at the default mu: exact, nobody fails.
+    (3) The stated limit: a four-leg robot (240 variables) with more than 160 active constraints -- mu = 0.2 on these states --
+    does not fit the re-solve's packed inverse (103 KB of the 160 KB LDS).  It is COUNTED as a failure; no robot outside
+    the tolerance goes uncounted."""
+    B = 48
+    cfg = MPCConfig.for_robot("ghost", horizon=20, mu=(0.2,) * 4)
+    state, cmd, t_off = _hard_states(cfg, B, seed=78)
+    probe = helpers.run_gpu(cfg, state, cmd, t_off, ticks=1, jitter=0.02)
+    two = np.where((probe[0]["stance_legs"] == 2) & (np.arange(B) % 2 == 0))[0]
+    assert two.size >= 8, two
+    s2, c2, t2 = _take(state, cmd, t_off, two)
+    orc = helpers.run_oracle(oracle_lib, cfg, s2, c2, t2, ticks=4, jitter=0.02)
+    gpu = helpers.run_gpu(cfg, s2, c2, t2, ticks=4, jitter=0.02)
+    for k, (g, o) in enumerate(zip(gpu, orc)):
+        legs2 = g["stance_legs"] == 2
+        assert (_torque_err(g, o)[legs2] <= TORQUE_REL_TOL).all(), (k, _torque_err(g, o))
+        assert (g["leg_state"] == o["leg_state"]).all()
+    assert (gpu[0]["stance_legs"] == 2).all() and gpu[0]["solver_stats"]["failures"] == 0
+    assert gpu[0]["solver_stats"]["retried_exact"] > 0, gpu[0]["solver_stats"]   # the hand-over happened
+    print("two-leg hand-overs per tick:", [g["solver_stats"]["retried_exact"] for g in gpu], "of", two.size)
+
+    cfg45 = MPCConfig.for_robot("ghost", horizon=20)
+    orc = helpers.run_oracle(oracle_lib, cfg45, state, cmd, t_off, ticks=6, jitter=0.02)
+    gpu = helpers.run_gpu(cfg45, state, cmd, t_off, ticks=6, jitter=0.02)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
+    assert sum(g["solver_stats"]["retried_exact"] for g in gpu) > 0
+
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=4, jitter=0.02)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=4, jitter=0.02)
+    for k, (g, o) in enumerate(zip(gpu, orc)):
+        bad = _torque_err(g, o) > TORQUE_REL_TOL
+        assert (g["stance_legs"][bad] == 4).all(), (k, np.where(bad)[0])
+        assert bad.sum() <= g["solver_stats"]["failures"], (k, int(bad.sum()), g["solver_stats"])
+    print("counted failures per tick (four legs, > 160 active constraints):", [g["solver_stats"]["failures"] for g in gpu])
+
+
 def test_warm_start_stays_within_tolerance(oracle_lib):
     """Warm start (the default): ADMM starts from the previous tick's iterate when the contact set is unchanged.
     Same tolerance as the cold solve; fewer iterations on slowly changing states."""
