@@ -71,6 +71,9 @@ struct DevCfg {
   int conv_feet_rotation, conv_com_height, conv_first_latch, conv_window_divide;   // recall-sensitive conventions (rg_mpc.h); alpha doubling is folded into `alpha`
   double Ntab[RG_MAXH * RG_MAXH];  // N_ab = H - max(a,b)
   double Stab[RG_MAXH * RG_MAXH];  // S_ab = sum_{k>max(a,b)}^{H} (k-a-1/2)(k-b-1/2)
+  // (appended: nothing above moves)
+  double *as_spill;          // horizon-20 re-solve: per-workgroup slabs of global memory for the rows of the packed (C_A G C_A')^-1 beyond the LDS part (SchedLds::SPILL doubles each); null: none
+  int as_spill_audit_base;   // first slab of the audit launch's workgroups (the re-solve launch uses 0 .. its grid - 1)
 };
 
 struct DevState {

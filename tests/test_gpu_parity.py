@@ -272,9 +272,8 @@ def test_horizon_20_exact_body_overflow_goes_to_the_retry_launch(oracle_lib):
     horizon-20 re-solve launch, whose room (120) a two-leg QP cannot outgrow: exact, nobody fails, also with mu = 0.2.  Under
     HYBRID no two-leg robot runs ADMM, so every re-solve counted on the two-leg-only batch IS such a hand-over.
     (2) The whole batch at the default mu: exact, nobody fails.
-    (3) The stated limit: a four-leg robot (240 variables) with more than 160 active constraints -- mu = 0.2 on these states --
-    does not fit the re-solve's packed inverse (103 KB of the 160 KB LDS).  It is COUNTED as a failure; no robot outside
-    the tolerance goes uncounted."""
+    (3) Four-leg robots (240 variables) with more than 160 active constraints -- mu = 0.2 on these states: the rows of the
+    packed inverse beyond the 160 the LDS holds go to the workgroup's slab of global memory; exact, nobody fails."""
     B = 48
     cfg = MPCConfig.for_robot("ghost", horizon=20, mu=(0.2,) * 4)
     state, cmd, t_off = _hard_states(cfg, B, seed=78)
@@ -301,11 +300,9 @@ def test_horizon_20_exact_body_overflow_goes_to_the_retry_launch(oracle_lib):
 
     orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, ticks=4, jitter=0.02)
     gpu = helpers.run_gpu(cfg, state, cmd, t_off, ticks=4, jitter=0.02)
-    for k, (g, o) in enumerate(zip(gpu, orc)):
-        bad = _torque_err(g, o) > TORQUE_REL_TOL
-        assert (g["stance_legs"][bad] == 4).all(), (k, np.where(bad)[0])
-        assert bad.sum() <= g["solver_stats"]["failures"], (k, int(bad.sum()), g["solver_stats"])
-    print("counted failures per tick (four legs, > 160 active constraints):", [g["solver_stats"]["failures"] for g in gpu])
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu), [g["solver_stats"] for g in gpu]
+    print("largest oracle working-set growth (constraint additions):", max(int(o["qp_iters"].max()) for o in orc))
 
 
 def test_warm_start_stays_within_tolerance(oracle_lib):
@@ -562,24 +559,20 @@ def test_randomised_configurations(oracle_lib, seed):
 
 
 @pytest.mark.parametrize("seed", [8635, 8727])
-def test_sweep_seeds_beyond_the_resolve_capacity_are_counted_failures(oracle_lib, seed):
-    """Seeds 8635 and 8727 of the sweep above (found by the 9000-seed evidence run, the only two that are not green): horizon 20,
+def test_sweep_seeds_with_more_active_constraints_than_the_lds_holds(oracle_lib, seed):
+    """Seeds 8635 and 8727 of the sweep above (found by the 9000-seed evidence run, the only two that were not green): horizon 20,
     constant contacts, one THREE-leg robot whose optimum sits on fz_min and the friction edge in almost every (step, leg)
-    block -- ~180 active constraints, more than the 160 the horizon-20 re-solve holds ("Room").  ADMM does not
-    converge on it either (not in 2000 iterations).  What the library promises there: the robot is COUNTED
-    (rg_mpc_last_solver_stats.failures) and every other robot of the batch is exact."""
+    block -- the oracle's own solver adds 247 / 213 constraints on it, ADMM does not converge in 2000 iterations.  The
+    horizon-20 re-solve keeps 160 rows of its packed inverse in LDS; the rows beyond live in the workgroup's slab of global
+    memory (SchedLds::SPILL), so these robots are exact like everybody else and nobody is counted as a failure."""
     cfg, B, over, kw = _sweep_case(seed)
     assert cfg.horizon == 20 and not cfg.contact_lookahead
     orc = helpers.run_oracle(oracle_lib, cfg, **kw)
     gpu = helpers.run_gpu(cfg, **kw)
-    seen = 0
-    for k, (g, o) in enumerate(zip(gpu, orc)):
-        bad = _torque_err(g, o) > TORQUE_REL_TOL
-        assert (g["stance_legs"][bad] >= 3).all(), (k, np.where(bad)[0], g["stance_legs"][bad])
-        assert bad.sum() <= g["solver_stats"]["failures"] <= 1, (k, int(bad.sum()), g["solver_stats"])
-        assert (g["leg_state"] == o["leg_state"]).all()
-        seen += int(bad.sum())
-    assert seen >= 1   # (if this fails the capacity has grown: move the seeds back into the plain sweep)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu), [g["solver_stats"] for g in gpu]
+    assert max(int(o["qp_iters"].max()) for o in orc) > 200   # (the scenario: a working set that outgrows the LDS part)
+    helpers.assert_audit_clean(gpu[-1]["audit"])
 
 
 def test_launch_order_independence(oracle_lib):
