@@ -36,6 +36,7 @@
 #include "rg_front_kernel.inc"
 #include "rg_qp_common.inc"
 #include "rg_qp_tile_kernel.inc"
+#include "rg_qp_sym6.inc"
 #include "rg_qp_wrench_kernel.inc"
 #include "rg_qp_exact_kernel.inc"
 #include "rg_qp_sched_kernel.inc"
