@@ -34,7 +34,7 @@ BATCH_PER_GPU = 4096
 HORIZON = 10
 EVENT_STRIDE = 4   # per-kernel HIP events are recorded on every 4th step of the timed region
 RING = 50          # state slabs in the input ring = ticks of one 0.5 s trot cycle (measured contacts stay gait-consistent)
-PROFILE_TAG = "r5"
+PROFILE_TAG = "r6"
 # algorithmic HBM bytes per controller step (kin_mode 0, all optional outputs off): inputs 320, persistent
 # controller state read + written ~550, the swing-IK hand-over (flags 32, target + start angles of ~1.5 swinging legs ~150),
 # action row 240
@@ -124,24 +124,51 @@ def compiled_sources(read=None):
     return dict(sorted(seen.items()))
 
 
-def source_hash(read=None):
+def strip_c_comments(data):
+    """C / C++ source bytes with every comment removed and every run of white space reduced to one blank (string and
+    character literals are left alone): what the compiler sees, as far as a hash needs to know."""
+    text = data.decode("utf-8", "replace")
+    out, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch == '"' or ch == "'":
+            j = i + 1
+            while j < n and text[j] != ch:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" "); i = n if j < 0 else j + 2
+        else:
+            out.append(ch); i += 1
+    import re
+    return re.sub(r"\s+", " ", "".join(out)).strip().encode()
+
+
+def source_hash(read=None, raw=False):
     """sha256 over the compiled kernel sources and the ABI header: ties committed profiles to the code they were measured on.
+    Comments and white space do NOT count (strip_c_comments): round 5 hashed the raw bytes, and a stale sentence in
+    include/rg_mpc.h then could not be fixed without orphaning the evidence that carried the hash.  raw=True: the round-5 form
+    (tests/test_evidence.py checks the round-5 files with it).
     read: see compiled_sources (a test hashes the sources of a COMMIT through `git show <commit>:<path>`)."""
     import hashlib
     h = hashlib.sha256()
     for rel, data in compiled_sources(read).items():
-        h.update(data)
+        h.update(data if raw else rel.encode() + b"\0" + strip_c_comments(data) + b"\0")
     return h.hexdigest()[:16]
 
 
-def source_hash_at(commit):
+def source_hash_at(commit, raw=False):
     """source_hash() of the tree of a commit (needs git and the history: not available on the GPU box)."""
     import subprocess
 
     def read(rel):
         r = subprocess.run(["git", "show", f"{commit}:{rel}"], cwd=ROOT, capture_output=True, timeout=30)
         return r.stdout if r.returncode == 0 else None
-    return source_hash(read)
+    return source_hash(read, raw)
 
 
 STAMP_FILE = os.path.join(ROOT, ".rg_source_commit")   # written by tools/stamp_commit.py before a gpurun call (the GPU box has no .git)

@@ -273,7 +273,7 @@ int rg_mpc_last_iterations(rg_mpc_handle *h, int32_t *iters_B, int32_t *stance_l
  * such robots, how many were handed to the exact solver (RG_SOLVER_AUTO: by ADMM at the iteration cap, or directly by the front
  * kernel, see rg_mpc_last_direct_count) and how many solves failed
  * (robots with a non-finite input or an out-of-range gait row -- counted once, given an all-zero command row and
- * left out of the QP --, active-set breakdowns (incl. more than 160 active constraints in the wrench-space exact pass),
+ * left out of the QP --, active-set breakdowns (iteration cap, a step that cannot be taken; the working set itself always has room),
  * plus, under RG_SOLVER_ADMM only, robots ADMM left unconverged). */
 int rg_mpc_last_solver_stats(rg_mpc_handle *h, int64_t *iters_sum, int32_t *iters_max, int32_t *qp_robots,
                              int32_t *retried, int32_t *failures, void *stream);

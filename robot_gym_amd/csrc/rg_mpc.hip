@@ -316,8 +316,8 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   rg_mpc_handle *h = new rg_mpc_handle();
   h->cfg = *cfg; h->B = batch; h->device = device;
   // Launch plans: front -> one QP launch over all stance-leg counts -> exact re-solve launch (normally empty).
-  //   RG_SOLVER_HYBRID (horizon 10, constant contacts): exact body for one / two legs, wrench-space ADMM for three / four;
-  //     at horizon 20 or with a contact schedule it is RG_SOLVER_AUTO (those QP bodies have no one-wave exact form).
+  //   RG_SOLVER_HYBRID (horizons 10 and 20, constant contacts): exact body for one / two legs, wrench-space ADMM for three /
+  //     four (horizon 20: the schedule body with a constant schedule); with a contact schedule it is RG_SOLVER_AUTO.
   //   RG_SOLVER_ACTIVE_SET (horizon 10): the same launch with three / four legs on the wrench-space exact body
   //     (qp_exact_wrench_robot); the re-solve launch only sees a working set that overflowed or a degenerate stance.  With
   //     a contact schedule every robot goes to the re-solve launch directly (front kernel plan 0: list = stance-leg bin).
