@@ -170,7 +170,11 @@ typedef struct {
   int32_t conv_com_height;      /* CoM height from the contact feet: 0: |mean z| ; 1: mean |z| */
   int32_t conv_first_latch;     /* 0: the first update after a reset does NOT latch a swing foot on a STANCE->SWING edge ; 1: it does */
   int32_t conv_window_divide;   /* velocity filter while its window fills: 0: divide by the window size ; 1: by the samples held */
-  int32_t reserved4;        /* must be 0 */
+  int32_t conv_friction_rows;   /* the four coefficients mu[0..3] when they DIFFER: 0: mu[l] is leg l's (upstream's name, foot_friction_coeffs) ;
+                                   1: mu[t] belongs to cone row t (-fx, +fx, -fy, +fy) of EVERY block -- how upstream's UpdateConstraintsMatrix
+                                   is recalled to use them.  Equal coefficients (every shipped robot: 0.45 x 4) make the two the same.
+                                   1 with unequal coefficients needs solver = RG_SOLVER_ACTIVE_SET (the ADMM bodies project onto a
+                                   symmetric pyramid).  (This field was reserved4, must-be-0, in earlier builds of ABI 5.) */
 } rg_mpc_config;
 #define RG_MPC_WIDE_BATCH 1024
 

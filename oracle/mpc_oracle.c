@@ -471,8 +471,11 @@ int orc_mpc_build_sched(const orc_config *c, const double rpy_in[3], const doubl
 /* (the REF cone rows' upper bound (mu+1) fz_max can never be active inside the box)      */
 /* ------------------------------------------------------------------------------------ */
 typedef struct { int i0, i1; double v0, v1, c0; } crow;
+/* conv_friction_rows with unequal coefficients: the coefficient of cone row ty (-fx, +fx, -fy, +fy) of EVERY block, set by
+ * orc_step around its QP solve; NULL: the block's (= its leg's) coefficient mu_blk[b].  Per thread, like the workspace. */
+static __thread const double *g_mu_rows = NULL;
 static crow make_row(int id, const double *mu_blk, double fz_lo, double fz_hi) {
-  int b = id / 6, ty = id % 6; crow r; double mu = mu_blk[b];
+  int b = id / 6, ty = id % 6; crow r; double mu = (g_mu_rows && ty < 4) ? g_mu_rows[ty] : mu_blk[b];
   switch (ty) {
     case 0: r.i0 = 3 * b;     r.v0 = -1; r.i1 = 3 * b + 2; r.v1 = mu; r.c0 = 0; break;
     case 1: r.i0 = 3 * b;     r.v0 = 1;  r.i1 = 3 * b + 2; r.v1 = mu; r.c0 = 0; break;
@@ -582,7 +585,7 @@ static int qp_admm_fixed(int n, const double *P, const double *qv, const double 
 static int orc_qp_solve_impl(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]) {
   const int nb = n / 3, m = 6 * nb;
   if (n == 0) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; return 0; }
-  if (g_qp_mode == 1) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; return qp_admm_fixed(n, P, qv, mu_blk, fz_lo, fz_hi, x); }
+  if (g_qp_mode == 1) { if (kkt) kkt[0] = kkt[1] = kkt[2] = 0; if (g_mu_rows) return -1; /* per-row coefficients: an asymmetric pyramid, exact solver only */ return qp_admm_fixed(n, P, qv, mu_blk, fz_lo, fz_hi, x); }
   double *L = ws_alloc(sizeof(double) * n * n), *J = ws_calloc((size_t)n * n, sizeof(double)), *R = ws_calloc((size_t)n * n, sizeof(double));
   double *d = ws_alloc(sizeof(double) * n), *z = ws_alloc(sizeof(double) * n), *r = ws_alloc(sizeof(double) * n);
   double *u = ws_calloc((size_t)m + 1, sizeof(double)), *s = ws_alloc(sizeof(double) * m);
@@ -681,6 +684,17 @@ static int orc_qp_solve_impl(int n, const double *P, const double *qv, const dou
 done:
   return ret;
 }
+/* ... with mu_rows[t] the coefficient of cone row t (-fx, +fx, -fy, +fy) of every block (conv_friction_rows) */
+int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]);
+int orc_qp_solve_rows(int n, const double *P, const double *qv, const double *mu_rows, double fz_lo, double fz_hi, double *x, double kkt[3]) {
+  double *mu_blk = (double *)malloc(sizeof(double) * (size_t)(n / 3 + 1));
+  for (int b = 0; b < n / 3; b++) mu_blk[b] = mu_rows[0];
+  g_mu_rows = mu_rows;
+  const int r = orc_qp_solve(n, P, qv, mu_blk, fz_lo, fz_hi, x, kkt);
+  g_mu_rows = NULL;
+  free(mu_blk);
+  return r;
+}
 int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk, double fz_lo, double fz_hi, double *x, double kkt[3]) {
   const size_t mark = ws_mark();   /* per-thread workspace: everything this call allocates is released on return */
   const int r = orc_qp_solve_impl(n, P, qv, mu_blk, fz_lo, fz_hi, x, kkt);
@@ -764,6 +778,7 @@ static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const 
   int contact[4];
   for (int leg = 0; leg < 4; leg++) contact[leg] = (s->desired[leg] == ORC_STANCE || s->desired[leg] == ORC_EARLY_CONTACT);
   int nc_guess = 0; for (int i = 0; i < 4; i++) nc_guess += contact[i];
+  const int rows_differ = c->conv_friction_rows && !(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]);
   double grf[12] = {0};
   if (c->contact_lookahead) {
     /* EXTENSION: step k uses the open-loop desired state at t + k dt_plan (k = 0 is the current tick) */
@@ -783,7 +798,9 @@ static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const 
       orc_mpc_build_sched(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, sched, in->cmd, P, qv, vs, vl);
       for (int b2 = 0; b2 < nb; b2++) mu_blk[b2] = c->mu[vl[b2]];   /* the block's leg */
       double mg = c->mass * c->gravity;
+      g_mu_rows = rows_differ ? c->mu : NULL;
       out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
+      g_mu_rows = NULL;
       int bad = out->qp_iters < 0;
       if (!bad) for (int b2 = 0; b2 < nb && vs[b2] == 0; b2++) for (int a = 0; a < 3; a++) grf[3 * vl[b2] + a] = -u[3 * b2 + a];
       if (bad) { return -1; }
@@ -796,11 +813,13 @@ static int orc_step_impl(const orc_config *c, orc_state *s, double t_now, const 
     int nc = orc_mpc_build(c, in->rpy, in->rpy_rate, s->v_body, (const double *)foot, contact, in->cmd, P, qv, legs, NULL, NULL);
     /* mu[l] is LEG l's friction coefficient (what the name foot_friction_coeffs says).  [UPSTREAM-RECALL]: the package's
      * UpdateConstraintsMatrix is recalled to put friction_coeff[0..3] on the four cone ROWS (-x, +x, -y, +y) of every block
-     * instead -- the same thing whenever the four are equal, as in every shipped config (0.45 x 4); with unequal values this
-     * restatement and the HIP path follow the per-leg meaning. */
+     * instead -- the same thing whenever the four are equal, as in every shipped config (0.45 x 4); with unequal values the
+     * reading is a switch (conv_friction_rows): 0 per leg, 1 per cone row. */
     for (int b = 0; b < n / 3; b++) mu_blk[b] = c->mu[legs[b % nc]];   /* blocks are ordered (step, contact-leg slot) */
     double mg = c->mass * c->gravity;
+    g_mu_rows = rows_differ ? c->mu : NULL;
     out->qp_iters = orc_qp_solve(n, P, qv, mu_blk, mg * c->fz_min_scale, mg * c->fz_max_scale, u, out->kkt);
+    g_mu_rows = NULL;
     if (out->qp_iters < 0) { return -1; }
     for (int l = 0; l < nc; l++) for (int a = 0; a < 3; a++) grf[3 * legs[l] + a] = -u[3 * l + a]; /* negated first step */
   }

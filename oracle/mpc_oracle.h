@@ -78,6 +78,7 @@ typedef struct {
   int conv_com_height;      /* 1: mean |z| of the contact feet instead of |mean z| */
   int conv_first_latch;     /* 1: the first update after a reset latches swing feet on a STANCE->SWING edge too */
   int conv_window_divide;   /* 1: the velocity window divides by the samples held while it fills, instead of by its size */
+  int conv_friction_rows;   /* 1: mu[t] is the coefficient of cone row t (-fx, +fx, -fy, +fy) of every block instead of leg t's (exact QP only) */
 } orc_config;
 
 typedef struct {
@@ -153,6 +154,8 @@ int orc_mpc_build_sched(const orc_config *c, const double rpy[3], const double o
 void orc_gait_desired(const orc_config *c, double t, int desired[4]);
 /* exact dual active-set solve of  min 1/2 u'Pu + q'u  s.t. friction pyramid + fz box per 3-block.
  * Returns iterations (<0 on failure). */
+/* the same with one friction coefficient per cone ROW (-fx, +fx, -fy, +fy) of every block: rg_mpc_config.conv_friction_rows */
+int orc_qp_solve_rows(int n, const double *P, const double *qv, const double *mu_rows, double fz_lo, double fz_hi, double *x, double kkt[3]);
 int orc_qp_solve(int n, const double *P, const double *qv, const double *mu_blk /* n/3 */, double fz_min, double fz_max,
                  double *u, double kkt[3]);
 

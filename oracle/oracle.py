@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("jxyz", ((d * 3) * 3) * 4), ("jrpy", ((d * 3) * 3) * 4), ("jaxis", ((d * 3) * 3) * 4),
         ("toe_xyz", (d * 3) * 4), ("toe_com", (d * 3) * 4), ("base_com", d * 3),
         ("ik_iters", i32), ("ik_damping", d), ("ik_max_step", d), ("kin_mode", i32), ("contact_lookahead", i32),
-        ("conv_alpha_doubled", i32), ("conv_feet_rotation", i32), ("conv_com_height", i32), ("conv_first_latch", i32), ("conv_window_divide", i32),
+        ("conv_alpha_doubled", i32), ("conv_feet_rotation", i32), ("conv_com_height", i32), ("conv_first_latch", i32), ("conv_window_divide", i32), ("conv_friction_rows", i32),
     ]
 
 
@@ -96,6 +96,8 @@ def lib():
         L.orc_mpc_build.restype = i32
         L.orc_qp_solve.argtypes = [i32, C.c_void_p, C.c_void_p, C.c_void_p, d, d, C.c_void_p, C.c_void_p]
         L.orc_qp_solve.restype = i32
+        L.orc_qp_solve_rows.argtypes = [i32, C.c_void_p, C.c_void_p, C.c_void_p, d, d, C.c_void_p, C.c_void_p]
+        L.orc_qp_solve_rows.restype = i32
         L.orc_leg_fk.argtypes = [C.POINTER(Config), i32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_leg_ik.argtypes = [C.POINTER(Config), i32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_leg_ik.restype = i32
@@ -199,13 +201,20 @@ def mpc_build(cfg, rpy, omega, v_body, foot_pos, contact, cmd):
     return P[:n, :n].copy(), q[:n].copy(), legs[:nc].copy(), Ad, Bd
 
 
-def qp_solve(P, q, mu, fz_min, fz_max):
+def qp_solve(P, q, mu, fz_min, fz_max, mu_rows=None):
+    """mu: one coefficient, or one per force block (3 variables each); mu_rows: instead, one per cone ROW (-fx, +fx, -fy, +fy)
+    of every block (rg_mpc_config.conv_friction_rows)."""
     n = len(q)
     P = np.ascontiguousarray(P, dtype=np.float64)
     q = np.ascontiguousarray(q, dtype=np.float64)
-    mu_blk = np.full(n // 3, mu, dtype=np.float64)
     u = np.zeros(n)
     kkt = np.zeros(3)
+    if mu_rows is not None:
+        rows = np.ascontiguousarray(mu_rows, dtype=np.float64)
+        assert rows.shape == (4,)
+        it = lib().orc_qp_solve_rows(n, _p(P), _p(q), _p(rows), fz_min, fz_max, _p(u), _p(kkt))
+        return u, it, kkt
+    mu_blk = np.ascontiguousarray(np.broadcast_to(np.asarray(mu, dtype=np.float64), (n // 3,)))
     it = lib().orc_qp_solve(n, _p(P), _p(q), _p(mu_blk), fz_min, fz_max, _p(u), _p(kkt))
     return u, it, kkt
 

@@ -88,7 +88,7 @@ class MPCConfig:
     conv_com_height: int = 0         # 1: mean |z| of the contact feet instead of |mean z|
     conv_first_latch: int = 0        # 1: the first update after a reset latches swing feet too
     conv_window_divide: int = 0      # 1: the filling velocity window divides by the samples held
-    reserved4: int = 0
+    conv_friction_rows: int = 0      # 1: unequal mu[0..3] belong to the four cone ROWS (-x, +x, -y, +y) of every block, not to the legs (needs solver ACTIVE_SET)
     # not part of the C struct: command offsets applied on the host (mpc_controller.py:90-95)
     vx_offset: float = 0.0
     vy_offset: float = 0.0

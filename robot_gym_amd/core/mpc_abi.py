@@ -40,7 +40,7 @@ class CConfig(C.Structure):
         ("accel_cos2", d), ("accel_rmax", d), ("accel_rmin", d), ("accel_rate_cap", d),
         ("audit_k", i32), ("reserved3", i32), ("audit_tol", d), ("admm_rho34_scale", d), ("admm_rho_sched_scale", d),
         ("lane_grid", i32), ("conv_alpha_doubled", i32), ("conv_feet_rotation", i32), ("conv_com_height", i32), ("conv_first_latch", i32),
-        ("conv_window_divide", i32), ("reserved4", i32),
+        ("conv_window_divide", i32), ("conv_friction_rows", i32),
     ]
 
 

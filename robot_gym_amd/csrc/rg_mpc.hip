@@ -220,15 +220,17 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   // the reference cannot set the horizon at all (mpc_controller.py:47-56 passes none: upstream default 10); 10 and 20
   // (BASELINE configs[4]) are the horizons with compiled and GPU-tested solver bodies
   if (c->horizon != 10 && c->horizon != 20) { err = "horizon must be 10 or 20"; return RG_MPC_ERR_INVALID; }
-  if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0 || c->reserved4 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
+  if (c->reserved0 != 0 || c->reserved2 != 0 || c->reserved3 != 0) { err = "reserved fields must be 0"; return RG_MPC_ERR_INVALID; }
   if (c->lane_grid < 0 || c->lane_grid > 2) { err = "lane_grid must be 0 (by batch), 1 (one wave per robot) or 2 (256 lanes per robot)"; return RG_MPC_ERR_INVALID; }
-  for (int v : {c->conv_alpha_doubled, c->conv_feet_rotation, c->conv_com_height, c->conv_first_latch, c->conv_window_divide})
+  for (int v : {c->conv_alpha_doubled, c->conv_feet_rotation, c->conv_com_height, c->conv_first_latch, c->conv_window_divide, c->conv_friction_rows})
     if (v != 0 && v != 1) { err = "convention switches (conv_*) are 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (!(c->accel_cos2 > 0 && c->accel_cos2 < 1) || !(c->accel_rmin > 0 && c->accel_rmin < c->accel_rmax && c->accel_rmax < 1) || !(c->accel_rate_cap > 0 && c->accel_rate_cap < 1)) { err = "extrapolation thresholds out of range: 0 < accel_cos2 < 1, 0 < accel_rmin < accel_rmax < 1, 0 < accel_rate_cap < 1"; return RG_MPC_ERR_INVALID; }
   if (c->audit_k < 0 || c->audit_k > RG_AUDIT_SLOTS / (2 * RG_AUDIT_PERIOD) || !(c->audit_tol > 0)) { err = "audit_k must be in [0, 16] and audit_tol positive"; return RG_MPC_ERR_INVALID; }
   if (!(c->admm_rho2 >= 0) || c->admm_switch < 0 || !(c->admm_extrap >= 0) || c->admm_accel < 0 || !(c->admm_rho34_scale > 0 && c->admm_rho34_scale <= 10) || !(c->admm_rho_sched_scale > 0 && c->admm_rho_sched_scale <= 10)) { err = "bad second-stage / convergence ADMM parameters"; return RG_MPC_ERR_INVALID; }
   if (c->window < 1 || c->window > 64) { err = "window out of range [1,64]"; return RG_MPC_ERR_INVALID; }
   for (int i = 0; i < 4; i++) if (!(c->mu[i] > 0 && c->mu[i] <= 100.0)) { err = "friction coefficients must be positive (and finite)"; return RG_MPC_ERR_INVALID; }
+  const bool mu_differ = !(c->mu[0] == c->mu[1] && c->mu[1] == c->mu[2] && c->mu[2] == c->mu[3]);
+  if (c->conv_friction_rows && mu_differ && c->solver != RG_SOLVER_ACTIVE_SET) { err = "conv_friction_rows = 1 with unequal friction coefficients (one per cone row: an asymmetric pyramid) needs solver = RG_SOLVER_ACTIVE_SET -- the ADMM bodies project onto a symmetric pyramid"; return RG_MPC_ERR_INVALID; }
   if (!(c->mass > 0) || !(c->dt_plan > 0) || !(c->alpha > 0)) { err = "mass, dt_plan and alpha must be positive"; return RG_MPC_ERR_INVALID; }
   if (c->kin_mode != 0 && c->kin_mode != 1) { err = "kin_mode must be 0 or 1"; return RG_MPC_ERR_INVALID; }
   if (c->solver != RG_SOLVER_ADMM && c->solver != RG_SOLVER_ACTIVE_SET && c->solver != RG_SOLVER_AUTO && c->solver != RG_SOLVER_HYBRID) { err = "unsupported solver"; return RG_MPC_ERR_INVALID; }
@@ -244,7 +246,8 @@ static int build_devcfg(const rg_mpc_config *c, DevCfg *d, std::string &err) {
   d->alpha = c->conv_alpha_doubled ? 2.0 * c->alpha : c->alpha;   // P = 2 (B'WB + alpha I) is the default form with twice the regulariser
   d->conv_feet_rotation = c->conv_feet_rotation; d->conv_com_height = c->conv_com_height; d->conv_first_latch = c->conv_first_latch; d->conv_window_divide = c->conv_window_divide;
   d->mu = c->mu[0]; d->g = c->gravity;
-  for (int i = 0; i < 4; i++) d->mu4[i] = c->mu[i];   // (per leg: read by the MU4 kernel instantiations only)
+  for (int i = 0; i < 4; i++) d->mu4[i] = c->mu[i];   // (per leg -- per cone row under conv_friction_rows: read by the MU4 kernel instantiations only)
+  d->mu_rows = (c->conv_friction_rows && mu_differ) ? 1 : 0;
   d->fz_min = c->mass * c->gravity * c->fz_min_scale; d->fz_max = c->mass * c->gravity * c->fz_max_scale;
   {
     const double *I = c->inertia;

@@ -74,6 +74,7 @@ struct DevCfg {
   // (appended: nothing above moves)
   double *as_spill;          // horizon-20 re-solve: per-workgroup slabs of global memory for the rows of the packed (C_A G C_A')^-1 beyond the LDS part (SchedLds::SPILL doubles each); null: none
   int as_spill_audit_base;   // first slab of the audit launch's workgroups (the re-solve launch uses 0 .. its grid - 1)
+  int mu_rows;               // rg_mpc_config.conv_friction_rows with unequal coefficients: mu4[t] belongs to cone row t (-x, +x, -y, +y) of EVERY block, not to leg t
 };
 
 struct DevState {
@@ -271,6 +272,12 @@ __device__ inline void leg_ik(const DevCfg *c, int leg, const double target[3], 
 template <bool MU4>
 __device__ __forceinline__ double leg_mu(const DevCfg *__restrict__ c, const int leg) {
   if constexpr (MU4) return c->mu4[leg & 3]; else return c->mu;
+}
+// ... of cone row `ty` (0: -fx, 1: +fx, 2: -fy, 3: +fy) of a block of leg `leg`: the exact bodies ask per constraint, so that
+// they can also follow the other recalled reading of upstream's four coefficients (conv_friction_rows: one per cone ROW)
+template <bool MU4>
+__device__ __forceinline__ double row_mu(const DevCfg *__restrict__ c, const int leg, const int ty) {
+  if constexpr (MU4) return c->mu4[(c->mu_rows ? ty : leg) & 3]; else return c->mu;
 }
 
 // Euclidean projection onto { |x| <= mu z, |y| <= mu z, lo <= z <= hi }.

@@ -248,11 +248,27 @@ def gen_qp(up, n_cases, rng):
                                        (0.0, 0.0, cfg.body_height), (c3[0], c3[1], 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, c3[2]))
         ins.append(np.concatenate([v, rpy, w, contact, feet, c3]))
         outs.append(np.asarray(f, dtype=np.float64))
-    return dict(inputs=np.array(ins), forces=np.array(outs), layout=np.array(["v_body[3] rpy[3] omega[3] contact[4] foot_pos[12] cmd(vx,vy,wz)[3]"])), dict(constructor_args_used=used, doc=str(getattr(mod.ConvexMpc, "__doc__", ""))[:2000])
+    # the same calls with UNEQUAL friction coefficients and harder commands (forces on their friction limits): the only vectors
+    # that can tell whether upstream's four coefficients go by leg or by cone row (rg_mpc_config.conv_friction_rows)
+    mu4 = [0.3, 0.45, 0.6, 0.5]
+    ins_mu, outs_mu = [], []
+    for b in range(n_cases):
+        contact = np.array([1, 1, 1, 1] if b % 3 == 0 else ([0, 1, 1, 0] if b % 3 == 1 else [1, 0, 0, 1]), dtype=np.int32)
+        rpy = state["rpy"][:, b].astype(np.float64).copy()
+        rpy[2] = 0.0
+        v = rng.uniform(-0.5, 0.5, 3)
+        w = state["rpy_rate"][:, b].astype(np.float64)
+        feet = state["foot_pos"][:, b].astype(np.float64)
+        c3 = 2.5 * cmd[:, b].astype(np.float64)
+        f = mpc.compute_contact_forces([0.0], list(v), list(rpy), list(w), [int(x) for x in contact], list(feet), list(mu4),
+                                       (0.0, 0.0, cfg.body_height), (c3[0], c3[1], 0.0), (0.0, 0.0, 0.0), (0.0, 0.0, c3[2]))
+        ins_mu.append(np.concatenate([v, rpy, w, contact, feet, c3]))
+        outs_mu.append(np.asarray(f, dtype=np.float64))
+    return dict(inputs=np.array(ins), forces=np.array(outs), inputs_mu=np.array(ins_mu), forces_mu=np.array(outs_mu), mu4=np.array(mu4), layout=np.array(["v_body[3] rpy[3] omega[3] contact[4] foot_pos[12] cmd(vx,vy,wz)[3]"])), dict(constructor_args_used=used, doc=str(getattr(mod.ConvexMpc, "__doc__", ""))[:2000])
 
 
 def pin():
-    """Run the comparison over all 32 convention settings and write the one that matches (tests/test_upstream_golden.py)."""
+    """Run the comparison over all 64 convention settings and write the one that matches (tests/test_upstream_golden.py)."""
     from tests.test_upstream_golden import best_conventions
     conv, err = best_conventions()
     json.dump(dict(conventions=conv, worst_error=err), open(os.path.join(HERE, "upstream_conventions.json"), "w"), indent=1)

@@ -69,7 +69,7 @@ def test_create_rejects_bad_config_before_touching_the_gpu():
                 dict(mu=(0.45, 0.45, -0.4, 0.45)), dict(mu=(0.0, 0.45, 0.45, 0.45)), dict(window=0), dict(kin_mode=2),
                 dict(solver=7), dict(solver=4), dict(admm_rho34_scale=0.0), dict(admm_rho_sched_scale=-1.0), dict(audit_k=1 << 27), dict(admm_relax=2.5), dict(motor_dir=(0.5,) * 12), dict(inertia=(0.0,) * 9),
                 dict(solver=1, horizon=20), dict(solver=1, contact_lookahead=1, horizon=20), dict(contact_lookahead=1, horizon=12),
-                dict(reserved0=1), dict(reserved0=32), dict(reserved2=1), dict(reserved3=1), dict(reserved4=1), dict(lane_grid=3), dict(lane_grid=-1),
+                dict(reserved0=1), dict(reserved0=32), dict(reserved2=1), dict(reserved3=1), dict(conv_friction_rows=2), dict(conv_friction_rows=1, mu=(0.3, 0.45, 0.6, 0.45)), dict(lane_grid=3), dict(lane_grid=-1),
                 dict(conv_alpha_doubled=2), dict(conv_feet_rotation=-1), dict(conv_com_height=2), dict(conv_first_latch=5), dict(conv_window_divide=2), dict(audit_k=-1), dict(audit_k=17), dict(audit_tol=0.0),
                 dict(accel_cos2=1.5), dict(accel_rmin=0.99), dict(accel_rate_cap=1.0), dict(admm_tol=-1.0), dict(admm_check=0), dict(admm_accel=-1)):
         cc = mpc_abi.make_cconfig(MPCConfig.for_robot("ghost", **bad))

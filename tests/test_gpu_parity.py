@@ -944,3 +944,36 @@ def test_per_leg_friction_coefficients(oracle_lib, case):
         f = -o["grf"].astype(np.float64).reshape(-1, 4, 3)
         lim = np.asarray(mu)[None, :] * f[:, :, 2]
         assert (np.abs(f[:, :, 0]) <= lim + 1e-3).all() and (np.abs(f[:, :, 1]) <= lim + 1e-3).all()
+
+
+@pytest.mark.parametrize("case", ["exact_everywhere", "exact_schedule"])
+def test_friction_coefficients_per_cone_row(oracle_lib, case):
+    """conv_friction_rows = 1: the OTHER recalled reading of upstream's four coefficients -- mu[t] belongs to
+    cone row t (-fx, +fx, -fy, +fy) of every block, an asymmetric pyramid -- as a config switch like the other conv_*: the exact
+    plan (RG_SOLVER_ACTIVE_SET: force space, wrench space, and the schedule body's active set) against the oracle with the same
+    setting; the setting changes the commands; every force stays inside the row-wise pyramid; equal coefficients make the two
+    readings the same (and run the uniform kernels, byte-identical: profiles/r6_isa_identity_friction_rows.txt); a plan with an ADMM body is
+    refused.  Reference for why it is a switch and not a guess: requirements.txt:8 (the arithmetic is not in the tree)."""
+    over = dict(exact_everywhere=dict(solver=1), exact_schedule=dict(solver=1, contact_lookahead=1))[case]
+    mu = (0.3, 0.45, 0.6, 0.5)
+    cfg = MPCConfig.for_robot("ghost", mu=mu, conv_friction_rows=1, **over)
+    state, cmd, t_off = synthetic.make_states(80, cfg, seed=67)
+    cmd = (cmd * np.float32(2.0)).astype(np.float32)   # harder commands: more robots on their friction limits
+    kw = dict(ticks=12, jitter=0.1)
+    orc = helpers.run_oracle(oracle_lib, cfg, state, cmd, t_off, **kw)
+    gpu = helpers.run_gpu(cfg, state, cmd, t_off, **kw)
+    _check(gpu, orc)
+    assert all(g["solver_stats"]["failures"] == 0 for g in gpu)
+    per_leg = helpers.run_oracle(oracle_lib, MPCConfig.for_robot("ghost", mu=mu, **over), state, cmd, t_off, **kw)
+    assert max(float(np.abs(a["grf"] - b["grf"]).max()) for a, b in zip(orc, per_leg)) > 1.0   # (N) the reading matters on these inputs
+    for o in gpu:   # -mu[1] fz <= fx <= mu[0] fz, -mu[3] fz <= fy <= mu[2] fz for the force the FOOT applies (grf = -f: the rows swap sides)
+        f = -o["grf"].astype(np.float64).reshape(-1, 4, 3)
+        fz = f[:, :, 2]
+        assert (f[:, :, 0] <= mu[0] * fz + 1e-3).all() and (-f[:, :, 0] <= mu[1] * fz + 1e-3).all()
+        assert (f[:, :, 1] <= mu[2] * fz + 1e-3).all() and (-f[:, :, 1] <= mu[3] * fz + 1e-3).all()
+    # equal coefficients: the switch changes nothing
+    eq1 = helpers.run_gpu(MPCConfig.for_robot("ghost", conv_friction_rows=1, **over), state, cmd, t_off, ticks=4, jitter=0.1)
+    eq0 = helpers.run_gpu(MPCConfig.for_robot("ghost", **over), state, cmd, t_off, ticks=4, jitter=0.1)
+    assert all(np.array_equal(a["action"], b["action"]) for a, b in zip(eq1, eq0))
+    with pytest.raises(Exception, match="conv_friction_rows"):
+        helpers.run_gpu(MPCConfig.for_robot("ghost", mu=mu, conv_friction_rows=1), state, cmd, t_off, ticks=1)

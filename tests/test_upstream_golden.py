@@ -21,7 +21,7 @@ from tests import helpers
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
-CONV = ("conv_alpha_doubled", "conv_feet_rotation", "conv_com_height", "conv_first_latch", "conv_window_divide")
+CONV = ("conv_alpha_doubled", "conv_feet_rotation", "conv_com_height", "conv_first_latch", "conv_window_divide", "conv_friction_rows")
 
 
 def _load(name):
@@ -78,6 +78,20 @@ def replay_qp(O, data, conv):
         for j, leg in enumerate(legs):
             f[3 * leg:3 * leg + 3] = -u[3 * j:3 * j + 3]   # the module returns the force the foot applies to the ground
         worst = max(worst, float(np.abs(f - np.asarray(f_up)[:12]).max()))
+    if "inputs_mu" in getattr(data, "files", data):   # unequal friction coefficients: by leg, or by cone row (conv_friction_rows)
+        mu4 = np.asarray(data["mu4"], dtype=np.float64)
+        for row, f_up in zip(data["inputs_mu"], data["forces_mu"]):
+            v, rpy, w, contact, feet, cmd = row[0:3], row[3:6], row[6:9], row[9:13].astype(np.int32), row[13:25], row[25:28]
+            P, q, legs, _, _ = O.mpc_build(ocfg, rpy, w, v, feet, contact, cmd)
+            if conv.get("conv_friction_rows"):
+                u, it, _ = O.qp_solve(P, q, None, fz_min, fz_max, mu_rows=mu4)
+            else:
+                u, it, _ = O.qp_solve(P, q, np.array([mu4[legs[b % len(legs)]] for b in range(len(q) // 3)]), fz_min, fz_max)
+            assert it >= 0
+            f = np.zeros(12)
+            for j, leg in enumerate(legs):
+                f[3 * leg:3 * leg + 3] = -u[3 * j:3 * j + 3]
+            worst = max(worst, float(np.abs(f - np.asarray(f_up)[:12]).max()))
     return worst
 
 
@@ -163,5 +177,28 @@ def test_comparison_machinery_on_stand_in_vectors(oracle_lib, tmp_path):
     assert w["states"] == 0 and w["tau"] == 0.0 and w["v_body"] == 0.0 and w["target"] == 0.0 and w["phase"] == 0.0, w
     w0 = replay_controller(O, loaded, 0, "ghost", dict.fromkeys(CONV, 0))
     assert w0["tau"] > 1e-3 or w0["v_body"] > 1e-3, w0
+    # ... and QP vectors in upstream_qp.npz's format with unequal friction coefficients, solved under the per-ROW reading
+    secret["conv_friction_rows"] = 1
+    qcfg = MPCConfig.for_robot("ghost", **secret)
+    qocfg = helpers.oracle_config(O, qcfg)
+    qstate, qcmd, _ = synthetic.make_states(9, qcfg, seed=7)
+    mu4 = np.array([0.3, 0.45, 0.6, 0.5])
+    fz_min, fz_max = qcfg.mass * qcfg.gravity * qcfg.fz_min_scale, qcfg.mass * qcfg.gravity * qcfg.fz_max_scale
+    ins, outs = [], []
+    for bq in range(9):
+        contact = np.array([1, 1, 1, 1] if bq % 3 == 0 else ([0, 1, 1, 0] if bq % 3 == 1 else [1, 0, 0, 1]), dtype=np.int32)
+        rpy = qstate["rpy"][:, bq].astype(np.float64).copy(); rpy[2] = 0.0
+        vq, wq, feet, c3 = np.array([0.3, -0.2, 0.05]), qstate["rpy_rate"][:, bq].astype(np.float64), qstate["foot_pos"][:, bq].astype(np.float64), 2.5 * qcmd[:, bq].astype(np.float64)
+        P, q, legs, _, _ = O.mpc_build(qocfg, rpy, wq, vq, feet, contact, c3)
+        u, it, _ = O.qp_solve(P, q, None, fz_min, fz_max, mu_rows=mu4)
+        assert it >= 0
+        f = np.zeros(12)
+        for j, leg in enumerate(legs):
+            f[3 * leg:3 * leg + 3] = -u[3 * j:3 * j + 3]
+        ins.append(np.concatenate([vq, rpy, wq, contact, feet, c3])); outs.append(f)
+    # (the equal-coefficient part of the file is exercised by the real vectors only: empty here)
+    np.savez(tmp_path / "upstream_qp.npz", inputs=np.zeros((0, 28)), forces=np.zeros((0, 12)), inputs_mu=np.array(ins), forces_mu=np.array(outs), mu4=mu4)
+    assert replay_qp(O, np.load(tmp_path / "upstream_qp.npz"), secret) == 0.0
+    assert replay_qp(O, np.load(tmp_path / "upstream_qp.npz"), dict(secret, conv_friction_rows=0)) > 1.0   # (N) by leg: other forces
     conv, err = best_conventions(oracle=O, gold_dir=str(tmp_path))
-    assert err == 0.0 and conv["conv_alpha_doubled"] == 1 and conv["conv_window_divide"] == 1 and conv["conv_feet_rotation"] == 0, (conv, err)
+    assert err == 0.0 and conv["conv_alpha_doubled"] == 1 and conv["conv_window_divide"] == 1 and conv["conv_feet_rotation"] == 0 and conv["conv_friction_rows"] == 1, (conv, err)

@@ -14,7 +14,7 @@ def kernels(path):
             if l.startswith('.Lfunc_end'):
                 out[name] = body; name = None
             elif l.startswith('\t') and not l.startswith('\t.') and not l.strip().startswith(';'):
-                body.append(re.sub(r'\.LBB\d+_', '.LBB_', l.split(';')[0].rstrip()))
+                body.append(re.sub(r'\.Lpost_getpc\d+', '.Lpost_getpc', re.sub(r'\.LBB\d+_', '.LBB_', l.split(';')[0].rstrip())))
     return out
 a, b = kernels(sys.argv[1]), kernels(sys.argv[2])
 for k in sorted(set(a) | set(b)):
