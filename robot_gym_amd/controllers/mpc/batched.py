@@ -23,10 +23,19 @@ class PackedState:
     (`contact` is the int32 view of its rows), then the offset-corrected command (`cmd`, 3 rows) -- so the gym
     side pays one H2D copy instead of ten."""
 
-    def __init__(self, batch, device, pin=None):
-        words = 2 + sum(c for _, c, _ in STATE_FIELDS) + 3
+    WORDS = 2 + sum(c for _, c, _ in STATE_FIELDS) + 3
+
+    def __init__(self, batch, device, pin=None, host_storage=None):
+        """host_storage: a flat float32 host tensor of WORDS * batch elements to use as the host slab (a slice of ONE pinned
+        buffer shared by the shards of a multi-device MPCVecEnv) instead of allocating one."""
+        words = self.WORDS
         pin = torch.cuda.is_available() if pin is None else pin
-        self.host_slab = torch.zeros(words, batch, dtype=torch.float32, pin_memory=pin)
+        if host_storage is not None:
+            if host_storage.dtype != torch.float32 or host_storage.numel() != words * batch or not host_storage.is_contiguous():
+                raise ValueError(f"host_storage must be a contiguous float32 tensor of {words * batch} elements")
+            self.host_slab = host_storage.view(words, batch)
+        else:
+            self.host_slab = torch.zeros(words, batch, dtype=torch.float32, pin_memory=pin)
         self.dev_slab = torch.zeros(words, batch, dtype=torch.float32, device=device)
         self.host, self.dev = {}, {}
         # the two clock rows hold B float64 values back to back (not one value per column)

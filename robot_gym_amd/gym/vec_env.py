@@ -36,6 +36,16 @@ workers write their state columns straight into one shared [82, B] slab and read
 slab; the parent makes the one rg_mpc_step in between.  One process per env, as in the reference, does not scale to the
 1024-4096 envs the GPU side is built for; a slice per worker does.
 
+`devices=[d0, d1, ...]` (the gym side of BASELINE configs[3], batch sharded over the GPUs of one node, SURVEY.md 8e "one handle +
+one stream per device"): the batch is cut into contiguous shards (core/sharding.shard_bounds), each with its own
+BatchedMPCController (handle) on its own stream of its device; the host keeps ONE pinned state buffer -- shard s owns the
+contiguous [82, n_s] block behind the blocks of the shards before it -- and ONE pinned [B, 60] action slab whose rows
+[lo_s, hi_s) shard s downloads into.  The host needs every action row anyway (PyBullet steps on the CPU), so one process
+driving N GPUs needs NO collective at all; all uploads and launches of a tick are enqueued before the first wait.  The same
+device may appear more than once (two handles and two streams on one GPU: how the CI box with one GPU tests this).
+One process per GPU instead: every rank builds an MPCVecEnv over ITS shard of the envs (shard_bounds(total, rank, world)) and
+calls core/sharding.all_gather_actions only if it wants every rank's rows (tests/test_host_logic.py, world size 2, gloo).
+
 Physics stays per-env on the CPU (PyBullet).  Clocks: robot b is stepped at env b's own GetTimeSinceReset() (per-robot
 clock array of the C-ABI), exactly like B separate reference controllers -- a partial reset never shifts another env.
 """
@@ -71,13 +81,15 @@ class _EnvGroup:
     """A contiguous slice [lo, lo + n) of the batch living in ONE process: phases 1 and 3 of a tick and the state gather
     for its envs.  The in-process wrapper owns one group over the whole batch; every worker process owns one over its slice."""
 
-    def __init__(self, envs, lo, views, clock, cmd, cfg, jacobian_fn):
+    def __init__(self, envs, lo, views, clock, cmd, cfg, jacobian_fn, base=None):
+        """lo: first column of this slice in `views`; base: batch index of its first env (default lo: the views span the batch)."""
         self.envs, self.lo, self.cfg = list(envs), lo, cfg
+        self.base = lo if base is None else base
         self.h, self.clock, self.cmd = views, clock, cmd
         self.slots = [env.simulation.controller for env in self.envs]
         for b, ctl in enumerate(self.slots):
             if not isinstance(ctl, BatchSlotController):
-                raise TypeError(f"env {lo + b}: simulation.controller is {type(ctl).__name__}; MPCVecEnv needs envs built with "
+                raise TypeError(f"env {self.base + b}: simulation.controller is {type(ctl).__name__}; MPCVecEnv needs envs built with "
                                 "controller_class=BatchSlotController (one slot of the batched GPU controller per env)")
         self.split = [hasattr(env, "pre_step") and hasattr(env, "post_step") for env in self.envs]
         self.one_pass = [not sp and hasattr(env, "resume_step") for sp, env in zip(self.split, self.envs)]   # split_step.one_pass classes
@@ -99,7 +111,7 @@ class _EnvGroup:
             except StepSuspended:
                 pass
             else:
-                raise RuntimeError(f"env {self.lo + b}: step() returned without asking its controller for an action")
+                raise RuntimeError(f"env {self.base + b}: step() returned without asking its controller for an action")
             finally:
                 ctl.phase = "idle"
 
@@ -121,7 +133,7 @@ class _EnvGroup:
         self.clock[lo:hi] = [env.simulation.GetTimeSinceReset() for env in self.envs]
         # lin = [vx + VX_OFFSET, vy + VY_OFFSET, 0], ang = wz + WZ_OFFSET (reference mpc_controller.py:90-95), float32
         self.cmd[:, lo:hi] = np.asarray([ctl.command for ctl in self.slots], dtype=np.float32).T + self.offsets
-        resets = [(lo + b, ctl.reset_clock) for b, ctl in enumerate(self.slots) if ctl.reset_clock is not None]
+        resets = [(self.base + b, ctl.reset_clock) for b, ctl in enumerate(self.slots) if ctl.reset_clock is not None]
         for ctl in self.slots:
             ctl.reset_clock = None
         return resets
@@ -224,13 +236,22 @@ class _Worker:
         return payload
 
 
+class _Shard:
+    """Rows [lo, hi) of the batch on one device: its controller handle, its block of the pinned state buffer, its stream."""
+
+    def __init__(self, lo, hi, controller, state, stream):
+        self.lo, self.hi, self.controller, self.state, self.stream = lo, hi, controller, state, stream
+
+
 class MPCVecEnv:
-    def __init__(self, envs=None, blocking=True, device=None, config=None, jacobian_fn=None, constructors=None, workers=None):
+    def __init__(self, envs=None, blocking=True, device=None, config=None, jacobian_fn=None, constructors=None, workers=None, devices=None):
         """envs: RobotGymEnv-like objects (`.simulation` with robot / controller / GetTimeSinceReset / ApplyStepAction,
         `step`, `reset`, `observation_space`, `action_space`) whose controller is a BatchSlotController -- stepped in this
         process (`blocking=True`, the reference's name for "one after another").
         blocking=False: pass `constructors` instead, one callable per env (picklable: the workers are spawned, never forked
-        from a process that holds a GPU context); `workers` processes (default min(8, B)) each build and step a slice."""
+        from a process that holds a GPU context); `workers` processes (default min(8, B)) each build and step a slice.
+        devices: HIP devices to shard the batch over, one controller handle and stream each (module docstring); default: the
+        one `device`."""
         self._blocking = bool(blocking)
         self._workers, self._shm = [], []
         if self._blocking:
@@ -277,17 +298,42 @@ class MPCVecEnv:
             self.cfg = config or hello[0][3]
         self._batch = B
         # the GPU context is created only now, after the workers were started
-        self.controller = BatchedMPCController(B, self.cfg, device=device, extra_outputs=False)
-        self._dev = self.controller.device
+        from robot_gym_amd.core.sharding import shard_bounds
+        devs = list(devices) if devices else [device]
+        if len(devs) > B:
+            raise ValueError(f"{len(devs)} devices for {B} envs")
         pin = torch.cuda.is_available()
-        self._state = PackedState(B, self._dev, pin)   # one pinned slab, one device slab, one copy per tick
+        # ONE pinned host buffer for the state of every shard (shard s: a contiguous [82, n_s] block) and ONE action slab
+        self._host_buffer = torch.zeros(SLAB_WORDS * B, dtype=torch.float32, pin_memory=pin)
         self._act_host = torch.zeros(B, 60, dtype=torch.float32, pin_memory=pin)
+        self._shards = []
+        for s, dv in enumerate(devs):
+            lo, hi = shard_bounds(B, s, len(devs))
+            ctl = BatchedMPCController(hi - lo, self.cfg, device=dv, extra_outputs=False)
+            state = PackedState(hi - lo, ctl.device, pin, host_storage=self._host_buffer[SLAB_WORDS * lo:SLAB_WORDS * hi])
+            stream = torch.cuda.Stream(device=ctl.device) if (ctl.device.type == "cuda" and len(devs) > 1) else None
+            self._shards.append(_Shard(lo, hi, ctl, state, stream))
+        self.controllers = [sh.controller for sh in self._shards]
+        self._dev, self._state = self.controller.device, self._shards[0].state
         if self._blocking:
-            views = {n: t.numpy() for n, t in self._state.host.items()}
-            self._group = _EnvGroup(self._envs, 0, views, self._state.host_clock.numpy(), self._state.host_cmd.numpy(), self.cfg, jacobian_fn)
-            self._slots = self._group.slots
+            self._groups = []
+            for sh in self._shards:
+                views = {n: t.numpy() for n, t in sh.state.host.items()}
+                self._groups.append(_EnvGroup(self._envs[sh.lo:sh.hi], 0, views, sh.state.host_clock.numpy(), sh.state.host_cmd.numpy(), self.cfg, jacobian_fn, base=sh.lo))
+            self._group = self._groups[0]
+            self._slots = [sl for g in self._groups for sl in g.slots]
         self.batched_calls = 0
         self._broken = None   # set when a tick failed half-way: the batch is then in no defined state
+
+    @property
+    def controller(self):
+        """The first shard's controller (the only one unless `devices` was given)."""
+        return self._shards[0].controller
+
+    @controller.setter
+    def controller(self, ctl):
+        self._shards[0].controller = ctl
+        self.controllers[0] = ctl
 
     @staticmethod
     def _check_slots(envs):
@@ -308,7 +354,7 @@ class MPCVecEnv:
     def __getattr__(self, name):
         """Forward unimplemented attributes to the first env (reference batch_env.py:52-61 forwards every name; with worker
         processes the request goes to the first worker, like ExternalProcess.__getattr__, wrappers.py:343-356)."""
-        if name in ("_envs", "_blocking", "_workers", "_shm", "_group", "_batch", "_broken"):   # not set yet: no recursion during __init__
+        if name in ("_envs", "_blocking", "_workers", "_shm", "_group", "_groups", "_shards", "_batch", "_broken"):   # not set yet: no recursion during __init__
             raise AttributeError(name)
         if self._blocking:
             return getattr(self._envs[0], name)
@@ -322,15 +368,21 @@ class MPCVecEnv:
 
     # ---------------------------------------------------------------------------------------------------------
     def _controller_call(self, resets):
-        """Phase 2: pending resets, ONE upload, ONE rg_mpc_step, ONE download.  Returns the [B, 60] host action rows."""
-        if resets:
-            self.controller.reset_at([t for _, t in resets], [b for b, _ in resets])
-        dev = self._state.upload(with_clock=True, with_cmd=True)
-        act = self.controller.get_action(0.0, dev)      # per-robot clocks travel in dev["t_robot"]
+        """Phase 2: pending resets, ONE upload, ONE rg_mpc_step, ONE download -- per shard, everything enqueued on every
+        shard's stream before the first wait.  Returns the [B, 60] host action rows."""
+        import contextlib
+        for sh in self._shards:
+            mine = [(b - sh.lo, t) for b, t in resets if sh.lo <= b < sh.hi]
+            with (torch.cuda.stream(sh.stream) if sh.stream is not None else contextlib.nullcontext()):
+                if mine:
+                    sh.controller.reset_at([t for _, t in mine], [b for b, _ in mine])
+                dev = sh.state.upload(with_clock=True, with_cmd=True)
+                act = sh.controller.get_action(0.0, dev)      # per-robot clocks travel in dev["t_robot"]
+                self._act_host[sh.lo:sh.hi].copy_(act, non_blocking=True)
         self.batched_calls += 1
-        self._act_host.copy_(act, non_blocking=True)
-        if self._dev.type == "cuda":
-            torch.cuda.current_stream(self._dev).synchronize()
+        for sh in self._shards:
+            if sh.controller.device.type == "cuda":
+                (sh.stream if sh.stream is not None else torch.cuda.current_stream(sh.controller.device)).synchronize()
         return self._act_host.numpy()
 
     def step(self, action):
@@ -367,9 +419,10 @@ class MPCVecEnv:
 
     def _step_unchecked(self, actions):
         if self._blocking:
-            self._group.pre(actions)
-            rows = self._controller_call(self._group.gather())
-            transitions = self._group.post(actions, rows)
+            for g, sh in zip(self._groups, self._shards):
+                g.pre(actions[sh.lo:sh.hi])
+            rows = self._controller_call([r for g in self._groups for r in g.gather()])
+            transitions = [tr for g, sh in zip(self._groups, self._shards) for tr in g.post(actions[sh.lo:sh.hi], rows[sh.lo:sh.hi])]
         else:
             try:
                 batch_actions = np.asarray(actions)          # one contiguous block per worker instead of n small pickles
@@ -380,7 +433,8 @@ class MPCVecEnv:
             for w in self._workers:   # phase 1 of every slice runs concurrently
                 w.conn.send((_STEP, batch_actions[w.lo:w.lo + w.n] if batch_actions is not None else [actions[i] for i in range(w.lo, w.lo + w.n)]))
             resets = [r for w in self._workers for r in w.receive(_READY)]
-            self._state.host_slab.numpy()[:] = self._shared_slab   # shared slab -> pinned slab (1.3 MB at B = 4096)
+            for sh in self._shards:   # shared slab -> the shards' blocks of the pinned buffer (1.3 MB at B = 4096)
+                sh.state.host_slab.numpy()[:] = self._shared_slab[:, sh.lo:sh.hi]
             self._shared_act[:] = self._controller_call(resets)
             for w in self._workers:   # ... and phase 3
                 w.conn.send((_ACT, None))
@@ -396,7 +450,12 @@ class MPCVecEnv:
             indices = np.arange(self._batch)
         indices = [int(i) for i in indices]
         if self._blocking:
-            return np.stack(self._group.reset(indices))
+            got = {}
+            for g, sh in zip(self._groups, self._shards):
+                mine = [i for i in indices if sh.lo <= i < sh.hi]
+                for i, o in zip(mine, g.reset([i - sh.lo for i in mine])):
+                    got[i] = o
+            return np.stack([got[i] for i in indices])
         per = {}
         for w in self._workers:   # non-blocking like the reference: every worker resets its share concurrently
             mine = [i - w.lo for i in indices if w.lo <= i < w.lo + w.n]
@@ -435,6 +494,6 @@ class MPCVecEnv:
             except FileNotFoundError:
                 pass
         self._shm = []
-        ctl = self.__dict__.get("controller")
-        if ctl is not None:
+        for ctl in self.__dict__.get("controllers", []):
             ctl.close()
+        self.__dict__["controllers"] = []

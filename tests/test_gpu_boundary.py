@@ -168,6 +168,43 @@ def test_vec_env_partial_reset_including_env_0(oracle_lib):
     venv.close()
 
 
+def test_vec_env_two_handles_on_one_gpu_match_one_handle():
+    """MPCVecEnv(devices=[0, 0]): the gym side of BASELINE configs[3] as far as one GPU can show it -- two controller handles
+    and two streams (here on the same device), contiguous shards of ONE pinned state buffer and ONE action slab, no collective --
+    gives bit-identical action rows to the single-handle wrapper over the same envs, a partial reset that crosses the shard
+    boundary included (envs 30 and 31 sit on either side of it).  include/rg_mpc.h: "a process driving several GPUs keeps one
+    handle per device"; API: reference agents/ppo/tools/batch_env.py:18-115."""
+    from robot_gym_amd.gym.vec_env import MPCVecEnv
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    cfg = MPCConfig.for_robot("ghost")
+    B = 62
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=23)
+    rng = np.random.default_rng(23)
+    acts = rng.uniform(-1, 1, (30, B, 2)).astype(np.float32)
+
+    def run(devices):
+        envs = [(SplitGoEnv if b % 2 else FakeGoEnv)(cfg, state, b, BatchSlotController) for b in range(B)]
+        venv = MPCVecEnv(envs, devices=devices)
+        venv.reset()
+        rows, obs = [], []
+        for k in range(30):
+            if k == 13:
+                venv.reset([5, 30, 31, 60])
+            o, r, d, info = venv.step(acts[k])
+            rows.append(np.stack([e.simulation.applied[-1] for e in envs]))
+            obs.append(o)
+        n = (len(venv.controllers), venv.batched_calls, [c.batch for c in venv.controllers])
+        venv.close()
+        return rows, obs, n
+    rows1, obs1, n1 = run(None)
+    rows2, obs2, n2 = run([0, 0])
+    assert n1 == (1, 30, [62]) and n2 == (2, 30, [31, 31])
+    for k, (a, b) in enumerate(zip(rows1, rows2)):
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+    assert all(np.array_equal(a, b) for a, b in zip(obs1, obs2))
+    assert np.isfinite(rows2[-1]).all() and np.abs(rows2[-1]).max() > 1.0   # real commands, not zeros
+
+
 def test_partial_reset_matches_fresh_controllers(oracle_lib):
     """rg_mpc_reset on a subset == new oracle controllers for that subset (LocomotionController.reset)."""
     from robot_gym_amd.controllers.mpc.batched import BatchedMPCController

@@ -545,3 +545,117 @@ def test_fake_simulation_clock_is_the_reference_clock():
         sim.ApplyStepAction(np.zeros(60))
         got.append(float(sim.GetTimeSinceReset()).hex())
     assert got == gold["after_each_tick_hex"]
+
+
+def test_vec_env_shards_the_batch_over_devices(monkeypatch):
+    """MPCVecEnv(devices=[...]): one controller handle per shard over contiguous slices of the batch (shard_bounds), ONE pinned
+    state buffer (shard s owns a contiguous [82, n_s] block of it) and ONE action slab; every shard's controller sees exactly
+    its envs' state columns, clocks and commands, and resets with LOCAL indices -- a partial reset that crosses the shard
+    boundary reaches both handles.  The envs see the same rows as under a single handle.  (CPU, recording controllers; the GPU
+    version with two handles on one device: tests/test_gpu_boundary.py.)  API kept: reference agents/ppo/tools/batch_env.py:18-115."""
+    import torch
+    from robot_gym_amd.gym import vec_env
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    from tests.fake_envs import FakeGoEnv
+    monkeypatch.setattr(vec_env, "BatchedMPCController", _RecordingBatchedController)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+    cfg = MPCConfig.for_robot("ghost")
+    B = 5
+    state, cmd, t_off = synthetic.make_states(B, cfg, seed=3)
+    actions = np.array([[0.9, 0.1], [0.3, 0.2], [-0.5, -0.9], [0.2, 0.0], [0.1, 0.3]], dtype=np.float32)
+
+    def run(devices):
+        envs = [FakeGoEnv(cfg, state, b, BatchSlotController) for b in range(B)]
+        venv = vec_env.MPCVecEnv(envs, config=cfg, devices=devices)
+        outs = [venv.step(actions) for _ in range(3)]
+        venv.reset([1, 2, 4])                     # crosses the boundary between shard 0 (envs 0, 1) and shard 1 (envs 2, 3)
+        outs.append(venv.step(actions))
+        return venv, envs, outs
+    one, envs1, outs1 = run(None)
+    three, envs3, outs3 = run([None, None, None])
+    assert [c.batch for c in three.controllers] == [2, 2, 1] and len(one.controllers) == 1 and three.controller is three.controllers[0]
+    assert three.batched_calls == one.batched_calls == 4
+    # one pinned buffer, shard blocks back to back
+    assert [sh.state.host_slab.data_ptr() - three._host_buffer.data_ptr() for sh in three._shards] == [0, 4 * 82 * 2, 4 * 82 * 4]
+    lo = 0
+    for ctl in three.controllers:
+        n = ctl.batch
+        assert ctl.resets[0] == ([0.0] * n, list(range(n)))                                           # construction: every slot, local indices
+        for k, call in enumerate(ctl.calls):
+            ref = one.controller.calls[k]
+            for name in ("rpy", "q", "contact", "cmd", "jac"):
+                assert torch.equal(call[name], ref[name][:, lo:lo + n]), (name, k)
+            assert torch.equal(call["t_robot"], ref["t_robot"][lo:lo + n])
+        lo += n
+    assert three.controllers[0].resets[-1] == ([0.0], [1]) and three.controllers[1].resets[-1] == ([0.0], [0]) and three.controllers[2].resets[-1] == ([0.0], [0])
+    assert one.controller.resets[-1] == ([0.0] * 3, [1, 2, 4])
+    # the envs applied the same commands (the recording controller's rows carry its LOCAL slot index in column 0)
+    for b in range(B):
+        a1, a3 = envs1[b].simulation.applied, envs3[b].simulation.applied
+        assert len(a1) == len(a3) == 4 and all(np.array_equal(x[1:4], y[1:4]) for x, y in zip(a1, a3))
+        assert a3[-1][0] == b - [0, 0, 2, 2, 4][b]
+    for o1, o3 in zip(outs1, outs3):
+        assert np.array_equal(o1[0], o3[0]) and np.array_equal(o1[1], o3[1]) and np.array_equal(o1[2], o3[2])
+    with pytest.raises(ValueError, match="devices for"):
+        vec_env.MPCVecEnv([FakeGoEnv(cfg, state, 0, BatchSlotController)], config=cfg, devices=[None, None])
+    three.close()
+    assert all(c.closed for c in three.controllers) or three.controllers == []
+
+
+class _FunctionBatchedController(_RecordingBatchedController):
+    """... whose action rows are a function of the state it was handed (so that ranks can be compared with one process)."""
+
+    def get_action(self, t, state):
+        import torch
+        act = torch.zeros(self.batch, 60)
+        act[:, 0:3] = state["cmd"].T
+        act[:, 3:6] = state["rpy"].T
+        act[:, 6] = state["t_robot"].to(torch.float32)
+        act[:, 7:19] = state["q"].T
+        return act
+
+
+def _sharded_env_worker(rank, world, port, tmp):
+    """One process per GPU, on the CPU: rank r steps ITS shard of the envs with its own MPCVecEnv and gathers every rank's rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from robot_gym_amd.gym import vec_env
+    from robot_gym_amd.controllers.mpc.slot_controller import BatchSlotController
+    from tests.fake_envs import FakeGoEnv
+    vec_env.BatchedMPCController = _FunctionBatchedController
+    torch.cuda.is_available = lambda: False
+    cfg = MPCConfig.for_robot("ghost")
+    total = 7                                                    # uneven shards: 4 + 3
+    state, cmd, t_off = synthetic.make_states(total, cfg, seed=5)
+    rng = np.random.default_rng(1)
+    acts = rng.uniform(-1, 1, size=(4, total, 2)).astype(np.float32)
+    lo, hi = shard_bounds(total, rank, world)
+    mine = vec_env.MPCVecEnv([FakeGoEnv(cfg, state, b, BatchSlotController) for b in range(lo, hi)], config=cfg)
+    whole = vec_env.MPCVecEnv([FakeGoEnv(cfg, state, b, BatchSlotController) for b in range(total)], config=cfg) if rank == 0 else None
+    ok = True
+    for k in range(4):
+        if k == 2:
+            mine.reset([i - lo for i in (1, 5) if lo <= i < hi])   # env 1 lives on rank 0, env 5 on rank 1
+            if whole is not None:
+                whole.reset([1, 5])
+        obs, rew, done, info = mine.step(acts[k, lo:hi])
+        rows = torch.from_numpy(mine._act_host.numpy().copy())
+        every = all_gather_actions(rows, total=total, schedule="direct" if k % 2 else "ring")   # only because every rank wants all rows
+        ok = ok and tuple(every.shape) == (total, 60) and torch.equal(every[lo:hi], rows)
+        if whole is not None:
+            o2 = whole.step(acts[k])
+            ok = ok and torch.equal(every, torch.from_numpy(whole._act_host.numpy())) and np.array_equal(o2[0][lo:hi], obs) and np.array_equal(o2[1][lo:hi], rew)
+    with open(os.path.join(tmp, f"r{rank}"), "w") as f:
+        f.write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_sharded_env_loop_world_size_2_gloo(tmp_path):
+    """BASELINE configs[3]'s gym side with one process per GPU (here: per CPU rank, gloo): each rank owns shard_bounds(total, rank,
+    world) envs and one MPCVecEnv over them -- no collective on the data path --, and the optional all-gather of the action
+    rows (both schedules, uneven shards) gives every rank what ONE MPCVecEnv over all envs computes, a partial reset on each
+    side of the shard boundary included.  Reference API: agents/ppo/tools/batch_env.py:18-115."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_env_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"r{r}").read() for r in range(2)] == ["ok", "ok"]
