@@ -351,12 +351,12 @@ def cpu_baseline(cfg, batch, budget_s=10.0, fixed_cmd=None, gait_seed=None, sche
     # BASELINE.md section 2 variants, bounded samples of the same inputs (a few seconds each):
     #   B0  one thread, a plain loop over robots -- the shape of the reference's CPU path (one Python controller object per env,
     #       reference controllers/mpc/mpc_controller.py:102-106 called from gym/robot_gym_env.py:120-121), minus the interpreter
-    #   B1  every host core, the SAME over-relaxed ADMM as the GPU kernels at the GPU's mean iteration count (dense Cholesky
+    #   B1  the best thread count of the search above, the SAME over-relaxed ADMM as the GPU kernels at the GPU's mean iteration count (dense Cholesky
     #       of P + rho I, two triangular solves and the pyramid projection per iteration) instead of the exact solver
     try:
         v0, n0 = timed(1, 3.0)
         O.set_qp_mode(1, max(1, int(round(gpu_mean_iters))), cfg.admm_rho, cfg.admm_relax)
-        all_cores = (os.cpu_count() or 1) if Bs >= 64 else 1
+        all_cores = cores if Bs >= 64 else 1   # the searched thread count (os.cpu_count() oversubscribes a cgroup-limited box: 256 threads on 16 CPUs ran at a third of the 32-thread rate)
         v1, n1 = timed(all_cores, 3.0)
         out["variants"] = {"B0_one_thread_exact_qp": {"value": v0, "cores": 1, "sample": f"{Bs} robots x {n0} ticks"},
                            "B1_all_cores_fixed_count_admm": {"value": v1, "cores": all_cores, "admm_iterations": int(round(gpu_mean_iters)),
@@ -379,6 +379,8 @@ def gpu_sclk_mhz(device_index=0):
     except Exception:
         pass
     cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+    if want is None and len([c for c in cards if glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input")) or os.path.exists(os.path.join(c, "pp_dpm_sclk"))]) > 1:
+        return None   # several cards expose a clock and torch does not say which one this device is: no guess
     if want is not None:
         match = [c for c in cards if os.path.basename(os.path.realpath(c)).lower().startswith(want)]
         if not match:
@@ -838,6 +840,7 @@ def main():
                          "issue_view": with_f64_rate(issue_view_from_profile(prof, names[dom]), dur_s),
                          "profile": (f"profiles/{prof['tag']}_* (same kernel sources)" if prof else "no committed rocprof summary for these kernel sources / this workload: traffic and issue_view are null"),
                          "kernel_ms": {n: round(x, 4) for n, x in zip(names + ["step_total"], kms) if n != "-"},
+                         "kernel_ms_note": "hipEvent windows of the profiled ticks: step_total spans four event records (~1 us of stream time each), which the timed region behind ms_per_step does not carry -- it can exceed ms_per_step by a few us",
                          "robots_per_stance_count": robots,
                          "note": "path is instruction-issue/latency-bound, not HBM-bound (SURVEY.md 7.3-2): see issue_view and DESIGN.md section 5"},
         }

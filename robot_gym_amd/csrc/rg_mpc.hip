@@ -352,10 +352,13 @@ int rg_mpc_create(const rg_mpc_config *cfg, int32_t batch, int32_t device, rg_mp
   CR(hipGetDeviceProperties(&prop, device));
   h->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   const size_t B = batch, W = cfg->window;
-  if (cfg->horizon == 20) {   // the horizon-20 re-solve keeps the rows of its packed inverse beyond the LDS part here: one slab per workgroup of the re-solve launch, then one per workgroup of the audit launch
+  // the horizon-20 re-solve keeps the rows of its packed inverse beyond the LDS part in global memory: one slab per workgroup of
+  // the re-solve launch, then one per workgroup of the audit launch (sched_retry_grid: the launcher's own grid rule).  Only
+  // for handles that can launch it (an exact re-solve behind ADMM, or the audit lane).
+  if (cfg->horizon == 20 && (cfg->solver != RG_SOLVER_ADMM || cfg->audit_k > 0)) {
     using Resolve20 = SchedLds<20, 4, true>;
-    h->hcfg.as_spill_audit_base = h->cu_count;
-    AL(h->hcfg.as_spill, (size_t)(h->cu_count + RG_AUDIT_SLOTS) * Resolve20::SPILL);
+    h->hcfg.as_spill_audit_base = sched_retry_grid(h->cu_count, batch, false, 0);
+    AL(h->hcfg.as_spill, (size_t)(h->hcfg.as_spill_audit_base + sched_retry_grid(h->cu_count, batch, true, cfg->audit_k * RG_AUDIT_PERIOD)) * Resolve20::SPILL);
   }
   AL(h->dcfg, 1);
   CR(hipMemcpy(h->dcfg, &h->hcfg, sizeof(DevCfg), hipMemcpyHostToDevice));

@@ -1,3 +1,4 @@
+#!/bin/bash
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 HDR=$(python3 tools/evidence_guard.py) || { echo "$HDR"; exit 1; }
 mkdir -p gpurun_out/r5_final
