@@ -1,5 +1,6 @@
 """Study (GPU): how often BASELINE configs[4] hands robots to the exact re-solve launch in steady state, and what those ticks cost
 (per-tick solver statistics, the host waits for every tick).  Round 6: a quarter of the ticks, 1-3 robots, +260 us on those ticks."""
+import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, bench
