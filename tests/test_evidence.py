@@ -24,7 +24,7 @@ ROUNDS = [("r5", True), ("r6", False)]   # (file prefix, hashed over raw bytes)
 
 
 # stand-alone studies (their own binaries, no library build behind them): described in LAB_NOTES.md, not tied to a library commit
-UNSTAMPED = {"r6_sweep_bench_study.txt", "r6_isa_identity_friction_rows.txt", "r6_config5_resolve_census.txt"}
+UNSTAMPED = {"r6_sweep_bench_study.txt", "r6_isa_identity_friction_rows.txt", "r6_config5_resolve_census.txt", "r6_accel_tail.txt"}
 
 
 def _git(*args):
