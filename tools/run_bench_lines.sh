@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun) AFTER profiles/ holds the summaries of the current kernel sources: the bench line of every
 # BASELINE workload, now carrying the profile-derived fields (roofline.traffic, roofline.issue_view).  -> gpurun_out/bench_<key>.json
 set -u
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 python3 tools/evidence_guard.py || exit 1
@@ -15,4 +15,4 @@ run config5 --horizon 20 --random-schedule
 run b32768 --batch 32768
 run kin1 --kin-mode 1
 run config2_grid1 --batch 1024 --fixed-cmd --lane-grid 1
-python3 tools/vec_env_bench.py 20 > gpurun_out/${TAG}_vec_env_host.txt 2> gpurun_out/${TAG}_vec_env_host.err; cat gpurun_out/${TAG}_vec_env_host.txt
+{ echo "# $(python3 tools/evidence_guard.py); tools/vec_env_bench.py 20"; python3 tools/vec_env_bench.py 20; } > gpurun_out/${TAG}_vec_env_host.txt 2> gpurun_out/${TAG}_vec_env_host.err; cat gpurun_out/${TAG}_vec_env_host.txt
