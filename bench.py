@@ -407,25 +407,31 @@ def dropin_latency(cfg, calls=300):
     """End-to-end latency of the drop-in plugin class, `MPCController.get_action()` at batch 1 (BASELINE configs[0]; the
     reference's bar is the playground's 10 ms control tick, playground/playground.py:122-126): the state gather through the
     reference's Robot getter names (a stub robot serving a synthetic state: PyBullet's own getter time is NOT in this number),
-    four Jacobian callbacks, one pinned host-to-device copy, the tick's three launches, the action row back and the stream
-    synchronisation."""
+    four Jacobian callbacks, the tick's three launches reading the pinned host slab and writing the action row into pinned
+    host memory themselves (zero copy, the default), and the stream synchronisation.  `copy_path`: the same with one upload
+    and one download around the launches (rg_mpc_step_host), the form of rounds 4-5."""
     from robot_gym_amd import synthetic
     from robot_gym_amd.controllers.mpc.mpc_controller import MPCController
     from tests.fake_envs import StubRobot
     state, cmd, _ = synthetic.make_states(1, cfg, seed=0)
-    clock = [0.0]
-    ctl = MPCController(StubRobot(cfg, state, 0), lambda: clock[0], config=cfg)
-    ctl.update_controller_params((0.3, 0.0, 0.0))
-    lat = []
-    for k in range(calls + 20):
-        clock[0] = 0.01 * k
-        t0 = time.perf_counter()
-        ctl.get_action()
-        lat.append(time.perf_counter() - t0)
-    ctl._batched.close()
-    lat = np.array(lat[20:]) * 1e6
-    return {"mean": round(float(lat.mean()), 1), "p50": round(float(np.median(lat)), 1), "p99": round(float(np.percentile(lat, 99)), 1),
-            "calls": calls, "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet), includes H2D, 3 launches, D2H, sync"}
+
+    def measure(zero_copy):
+        clock = [0.0]
+        ctl = MPCController(StubRobot(cfg, state, 0), lambda: clock[0], config=cfg, zero_copy=zero_copy)
+        ctl.update_controller_params((0.3, 0.0, 0.0))
+        lat = []
+        for k in range(calls + 20):
+            clock[0] = 0.01 * k
+            t0 = time.perf_counter()
+            ctl.get_action()
+            lat.append(time.perf_counter() - t0)
+        ctl._batched.close()
+        lat = np.array(lat[20:]) * 1e6
+        return {"mean": round(float(lat.mean()), 1), "p50": round(float(np.median(lat)), 1), "p99": round(float(np.percentile(lat, 99)), 1)}
+    out = measure(True)
+    out.update({"calls": calls, "copy_path": measure(False),
+                "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet): 3 launches on the pinned host slab (zero copy) + sync; copy_path: H2D, 3 launches, D2H, sync"})
+    return out
 
 
 def self_launch(args, argv):

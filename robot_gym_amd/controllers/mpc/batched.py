@@ -169,10 +169,14 @@ class BatchedMPCController:
         self._handle.step(t, sp, self._out, self._stream())
         return self.action
 
-    def bind_host_state(self, packed: "PackedState", action_host):
+    def bind_host_state(self, packed: "PackedState", action_host, zero_copy=False):
         """Prepare the host-resident fast path (get_action_host): validate ONCE that `packed` (a PackedState of this batch
         on this device, pinned) and `action_host` (pinned float32 [B,60]) fit, and build the pointer structs the per-tick
-        call reuses -- the per-tick path then is one call across the C-ABI (rg_mpc_step_host)."""
+        call reuses -- the per-tick path then is one call across the C-ABI (rg_mpc_step_host).
+        zero_copy: the kernels read the state straight from the pinned host slab and write the action row straight into
+        `action_host` (pinned host memory is device-accessible through its own address on ROCm): no upload, no download --
+        for a batch of one or a few robots the two copy operations cost more stream time (~6 us each) than the 568 bytes
+        take over PCIe inside the kernels.  The tick is then rg_mpc_step + a stream synchronisation."""
         if packed.dev_slab.device != self.device or tuple(packed.dev_slab.shape[1:]) != (self.batch,) or not packed.host_slab.is_pinned():
             raise ValueError("bind_host_state: PackedState of another batch / device, or not pinned")
         if action_host.dtype != torch.float32 or tuple(action_host.shape) != (self.batch, 60) or not action_host.is_pinned() or not action_host.is_contiguous():
@@ -184,6 +188,18 @@ class BatchedMPCController:
             setattr(sp, name, packed.dev[name].data_ptr())
         self._host_bound = (sp, packed, action_host, packed.host_slab.data_ptr(), packed.dev_slab.data_ptr(),
                             packed.host_slab.numel() * packed.host_slab.element_size(), action_host.data_ptr())
+        self._zero_copy = None
+        if zero_copy:
+            spz = mpc_abi.CStatePtrs()
+            for name, comps, dt in STATE_FIELDS:
+                if name in ("foot_pos", "jac") and self.cfg.kin_mode == 1:
+                    continue
+                setattr(spz, name, packed.host[name].data_ptr())
+            outz = mpc_abi.COutPtrs()
+            outz.action = action_host.data_ptr()
+            for k, v in self.extra.items():
+                setattr(outz, k, v.data_ptr())
+            self._zero_copy = (spz, outz)
 
     def get_action_host(self, t):
         """One tick from the bound host slab: upload, step, download, wait (rg_mpc_step_host).  Returns the bound pinned
@@ -191,6 +207,11 @@ class BatchedMPCController:
         if getattr(self, "_host_bound", None) is None:
             raise RuntimeError("get_action_host: call bind_host_state(packed_state, pinned_action) first")
         sp, packed, action_host, hptr, dptr, nbytes, aptr = self._host_bound
+        if self._zero_copy is not None:
+            spz, outz = self._zero_copy
+            self._handle.step(t, spz, outz, self._stream())
+            torch.cuda.current_stream(self.device).synchronize()
+            return action_host
         self._handle.step_host(t, hptr, dptr, nbytes, sp, self._out, aptr, self._stream())
         return action_host
 

@@ -48,7 +48,10 @@ def config_from_robot(robot, robot_name=None, **overrides):
 class MPCController(Controller):
     MOTOR_CONTROL_MODE = MOTOR_CONTROL_HYBRID
 
-    def __init__(self, robot, get_time_since_reset, device=None, config=None):
+    def __init__(self, robot, get_time_since_reset, device=None, config=None, zero_copy=True):
+        """zero_copy (default): the tick's kernels read the robot's state from the pinned host slab and write the action row
+        into pinned host memory themselves (BatchedMPCController.bind_host_state); False: one upload, the launches, one
+        download (rg_mpc_step_host)."""
         super().__init__(robot, get_time_since_reset)
         self._cfg = config or config_from_robot(robot)
         self._chain = ChainKinematics(self._cfg)
@@ -58,7 +61,7 @@ class MPCController(Controller):
         self._state = PackedState(1, self._dev)     # one pinned slab: one H2D copy per tick instead of eight
         self._host = {n: t.numpy() for n, t in self._state.host.items()}
         self._act_host = torch.zeros(1, 60, dtype=torch.float32, pin_memory=True)
-        self._batched.bind_host_state(self._state, self._act_host)   # per tick: one call across the C-ABI (rg_mpc_step_host)
+        self._batched.bind_host_state(self._state, self._act_host, zero_copy=zero_copy)   # per tick: one call across the C-ABI
         self._act_np = self._act_host[0].numpy()
         # column views of the one robot's slab entries, made once (batch 1: every field's column is contiguous)
         self._col = {n: a[:, 0] for n, a in self._host.items()}
