@@ -425,12 +425,17 @@ def dropin_latency(cfg, calls=300):
             t0 = time.perf_counter()
             ctl.get_action()
             lat.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for k in range(calls):
+            ctl._gather_state()
+        gather = (time.perf_counter() - t0) / calls * 1e6
         ctl._batched.close()
         lat = np.array(lat[20:]) * 1e6
-        return {"mean": round(float(lat.mean()), 1), "p50": round(float(np.median(lat)), 1), "p99": round(float(np.percentile(lat, 99)), 1)}
+        return {"mean": round(float(lat.mean()), 1), "p50": round(float(np.median(lat)), 1), "p99": round(float(np.percentile(lat, 99)), 1),
+                "state_gather_mean": round(gather, 1)}
     out = measure(True)
     out.update({"calls": calls, "copy_path": measure(False),
-                "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet): 3 launches on the pinned host slab (zero copy) + sync; copy_path: H2D, 3 launches, D2H, sync"})
+                "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet): 3 launches on the pinned host slab (zero copy) + sync; copy_path: H2D, 3 launches, D2H, sync.  state_gather_mean: the part of it spent in the robot's getters and the four calculateJacobian callbacks before the library is called (~20 us of that is the STUB building an 18-column Jacobian as Python lists, tests/fake_envs.py -- host Python, neither the library nor PyBullet)"})
     return out
 
 
