@@ -435,7 +435,7 @@ def dropin_latency(cfg, calls=300):
                 "state_gather_mean": round(gather, 1)}
     out = measure(True)
     out.update({"calls": calls, "copy_path": measure(False),
-                "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet): 3 launches on the pinned host slab (zero copy) + sync; copy_path: H2D, 3 launches, D2H, sync.  state_gather_mean: the part of it spent in the robot's getters and the four calculateJacobian callbacks before the library is called (~20 us of that is the STUB building an 18-column Jacobian as Python lists, tests/fake_envs.py -- host Python, neither the library nor PyBullet)"})
+                "what": "MPCController.get_action() wall time per call, stub robot getters (no PyBullet): 3 launches on the pinned host slab (zero copy) + sync; copy_path: H2D, 3 launches, D2H, sync.  state_gather_mean: the part of it spent in the robot's getters and the four calculateJacobian callbacks before the library is called (three quarters of that is the STUB building an 18-column Jacobian as Python lists, tests/fake_envs.py -- host Python, neither the library nor PyBullet)"})
     return out
 
 
